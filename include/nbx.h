@@ -1,0 +1,155 @@
+/*
+ * nbx.h -- C-ABI of libnbx.so: the MI355X (gfx950) implementation of the
+ * GSimulation::start() hot path of NTHU-SC/nbody-demo-2023.
+ *
+ * Drop-in boundary.  In the reference the plug-in point is "a translation unit
+ * that defines void GSimulation::start()" (ver5_all/Makefile:104,
+ * ver5_all/programming_models/hip/Compute.cpp:65; inline in ver7 at
+ * ver7/GSimulation.cpp:96-242).  Everything start() does per time step lives
+ * behind the entry points below; the host keeps allocation of the ParticleSoA
+ * arrays, the init_* functions, timing and printing (see INTEGRATION.md for the
+ * start() a maintainer would write against this header).
+ *
+ * Conventions: plain C, no C++/torch types; every function returns an int
+ * status (NBX_OK == 0, negative = error, text via nbx_last_error()); no
+ * exception crosses the boundary.  A context is driven by one host thread at a
+ * time.  All host arrays are caller-owned SoA arrays of `n` elements of the
+ * context's precision (float for 32, double for 64), exactly the reference's
+ * ParticleSoA members (ver7/Particle.hpp:43-58).
+ */
+#ifndef NBX_H
+#define NBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBX_ABI_VERSION 1
+
+enum {
+  NBX_OK = 0,
+  NBX_ERR_ARG = -1,     /* null pointer, n <= 0, precision not in {32,64}, bad slice ... */
+  NBX_ERR_DEVICE = -2,  /* no HIP device / HIP runtime error (text in nbx_last_error) */
+  NBX_ERR_STATE = -3,   /* call out of order (e.g. step before upload) */
+  NBX_ERR_ALLOC = -4
+};
+
+/* kernel_variant values */
+enum {
+  NBX_KERNEL_AUTO = 0,
+  NBX_KERNEL_LDS = 1,  /* j-tile staged in LDS, broadcast ds_read_b128 (the north-star design) */
+  NBX_KERNEL_SGPR = 2  /* j-bodies fetched by wave-uniform scalar loads into SGPRs */
+};
+
+typedef struct nbx_ctx nbx_ctx;
+
+/*
+ * Options (all zero == defaults).  Replaces the compile-time / argv knobs of the
+ * reference's GPU back ends: block size argv[5] (hip/Compute.cpp:133-139), the
+ * MPI slice [start,end) (cpu/Compute.cpp:47-58), real_type (types.hpp:21).
+ */
+typedef struct nbx_opts {
+  int32_t struct_size;     /* = sizeof(nbx_opts); 0 is accepted as "this version" */
+  int32_t device;          /* HIP device ordinal; -1 = keep the current device */
+  void*   stream;          /* hipStream_t to enqueue on; NULL = the context creates its own */
+  int32_t i_begin;         /* first body this context owns (integrates) */
+  int32_t i_count;         /* bodies owned; 0 = all n (single-GPU) */
+  int32_t n_alloc;         /* length of the device {x,y,z,G*m} array, >= n; 0 = n rounded up to the
+                              j-tile.  Ranks of one job pass the same value (= ranks * block). */
+  int32_t bodies_per_lane; /* register blocking of i-bodies: 1,2,4,8; 0 = auto */
+  int32_t j_split;         /* workgroups sharing one i-block, each summing a j-range; 0 = auto */
+  int32_t kernel_variant;  /* NBX_KERNEL_* */
+  int32_t fused_epilogue;  /* 1: integrate in the force kernel when j_split==1; 0: separate kernel;
+                              -1/unset(0 with struct_size==0) = auto */
+  int32_t use_graph;       /* 1: replay multi-step windows from a hipGraph; 0: plain launches */
+  int32_t reserved[5];
+} nbx_opts;
+
+typedef struct nbx_stats_t {
+  int32_t n, n_alloc, i_begin, i_count, precision;
+  int32_t bodies_per_lane, j_split, j_tile, kernel_variant, fused_epilogue;
+  int32_t force_grid_x, force_grid_y, force_block;
+  int32_t cu_count, clock_mhz;
+  int64_t steps_done;          /* time steps executed since create */
+  int64_t force_launches_timed;/* force-kernel launches covered by force_ms_total */
+  double  force_ms_total;      /* sum of HIP-event durations of those launches (profiling on) */
+  double  pairs_per_launch;    /* i_count * n */
+  char    device_name[64];
+} nbx_stats_t;
+
+/* Text of the last error on the calling thread ("" if none). Never NULL. */
+const char* nbx_last_error(void);
+int32_t nbx_abi_version(void);
+
+/*
+ * Create a context for n bodies at `precision` (32 | 64).  Allocates all device
+ * state; replaces hipMalloc x7 + host aligned_alloc of hip/Compute.cpp:71-104.
+ */
+int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts);
+void nbx_destroy(nbx_ctx* ctx); /* NULL-safe */
+
+/*
+ * Host SoA -> device.  Replaces the per-step H2D copies of hip/Compute.cpp:111-119,148-150
+ * (done ONCE here; state then stays resident).  All seven arrays have n elements; positions
+ * and mass of ALL bodies are read, velocities only of the owned slice.  Packs {x,y,z,G*m} and
+ * {vx,vy,vz,m} with G = 6.67259e-11f (ver7/GSimulation.cpp:127).
+ */
+int nbx_upload(nbx_ctx* ctx, const void* pos_x, const void* pos_y, const void* pos_z,
+               const void* vel_x, const void* vel_y, const void* vel_z, const void* mass);
+
+/*
+ * nsteps time steps of ver7/GSimulation.cpp:138-200 (acceleration over all pairs, then
+ * v += a*dt; x += v*dt; kinetic energy).  Asynchronous unless kenergy_out != NULL, in which
+ * case it synchronises and stores _kenergy (= 0.5 * sum m v^2, ver7:200) after the LAST step.
+ * Only valid when the context owns all n bodies (no exchange step needed).
+ */
+int nbx_step(nbx_ctx* ctx, double dt, int32_t nsteps, double* kenergy_out);
+
+/* As nbx_step, but stores _kenergy after EVERY step into ke_trace[0..nsteps) and synchronises. */
+int nbx_step_trace(nbx_ctx* ctx, double dt, int32_t nsteps, double* ke_trace);
+
+/*
+ * Sharded stepping (one context per GPU, block partition over i as in the reference's MPI
+ * slices, cpu/Compute.cpp:47-58, and OpenCL device split, opencl/Compute.cpp:241-255):
+ *   nbx_step_local  : forces of the owned slice against all n_alloc resident bodies, then the
+ *                     Euler update of the owned slice into the NEXT position buffer.
+ *   nbx_exchange_buffer : device pointer / sizes of that NEXT buffer so the caller can run the
+ *                     in-place all-gather (RCCL ncclAllGather / torch.distributed) on `stream`.
+ *   nbx_commit      : make NEXT current.
+ *   nbx_kenergy_partial : sum over owned bodies of m*v^2 after the last local step (synchronises);
+ *                     the caller adds the partials over ranks and multiplies by 0.5.
+ */
+int nbx_step_local(nbx_ctx* ctx, double dt);
+int nbx_exchange_buffer(nbx_ctx* ctx, void** dev_ptr, size_t* total_bytes, size_t* own_offset_bytes,
+                        size_t* own_bytes);
+int nbx_commit(nbx_ctx* ctx);
+int nbx_kenergy_partial(nbx_ctx* ctx, double* sum_mv2);
+
+/*
+ * Accelerations of the owned bodies at the CURRENT positions, without integrating -- the
+ * whole job of the reference's GPU kernels (hip/Compute.cpp:27-62 + D2H :160-162).
+ * acc_* are host arrays of n elements; only [i_begin, i_begin+i_count) is written.
+ */
+int nbx_accel(nbx_ctx* ctx, void* acc_x, void* acc_y, void* acc_z);
+
+int nbx_sync(nbx_ctx* ctx);
+
+/*
+ * Device -> host SoA: positions of all n bodies (current buffer), velocities of the owned slice.
+ * Any pointer may be NULL to skip that array.  Leaves `particles->*` as the reference's start()
+ * leaves them (ver7/GSimulation.cpp:179-198).
+ */
+int nbx_download(nbx_ctx* ctx, void* pos_x, void* pos_y, void* pos_z, void* vel_x, void* vel_y,
+                 void* vel_z);
+
+/* Per-launch HIP-event timing of the force kernel (on the context's stream). */
+int nbx_profile(nbx_ctx* ctx, int32_t enable);
+int nbx_stats(nbx_ctx* ctx, nbx_stats_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBX_H */

@@ -1,0 +1,301 @@
+// nbx_kernels.hpp -- hand-written HIP kernels for gfx950 (MI355X, CDNA4).
+//
+// The per-time-step work of the reference's GSimulation::start()
+// (ver7/GSimulation.cpp:138-200):
+//   force_kernel      all-pairs softened-gravity acceleration   (ver7:141-177)
+//   integrate_kernel  v += a*dt; x += v*dt; m*v^2 partial sums  (ver7:178-198)
+//   ke_reduce_kernel  ordered final sum of the partials         (ver7:179,200)
+//
+// Data layout in HBM (all resident for the lifetime of a context):
+//   posm[2][n_alloc]  {x, y, z, G*m}   one 16 B (fp32) / 32 B (fp64) record per body, double
+//                     buffered: step s reads posm[cur] (every body, as j) and writes the owned
+//                     slice of posm[cur^1]; entries >= n are {0,0,0,0} (zero mass => the pair term
+//                     is exactly 0, so tiles need no bounds checks).
+//   velm[own]         {vx, vy, vz, m}  owned slice only; velocities never leave their owner.
+//   accp[S][own_pad]  {ax, ay, az, -}  partial accelerations when S workgroups split the j range.
+//   ke_part[blocks]   fp64 block partials of sum m*v^2, reduced in fixed order (deterministic).
+//
+// Execution shape: 256-thread workgroups (4 wave64, one per SIMD).  Each lane keeps B i-bodies
+// in registers (register blocking: one j record feeds B independent 13-instruction chains, which
+// hides the v_rsq_f32 latency and amortises the j fetch).  The j records come either from an LDS
+// tile (256 records, double buffered, every lane reads the same address => broadcast
+// ds_read_b128, no bank conflicts) or from wave-uniform scalar loads (s_load_dwordx4..16 into
+// SGPRs: costs neither LDS bandwidth nor VGPRs).  No MFMA: the pair kernel is rsqrt/FMA-chain
+// bound and its contraction forms cancel catastrophically in fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace nbx {
+
+constexpr int kBlock = 256;  // threads per workgroup
+constexpr int kTile = 256;   // j records per LDS tile (BASELINE.json configs[1]: "LDS j-tile=256")
+
+template <typename T> struct V4;
+template <> struct V4<float> { using type = float4; };
+template <> struct V4<double> { using type = double4; };
+
+// ver7/GSimulation.cpp:126-127; the fp64 variant widens the float literals.
+template <typename T> __host__ __device__ constexpr T softening2() { return (T)1.e-3f; }
+template <typename T> __host__ __device__ constexpr T grav_const() { return (T)6.67259e-11f; }
+
+// 1/sqrt(x).  fp32: the raw v_rsq_f32 (<= 1 ulp; r2 >= 1e-3 so no denormal/zero handling is
+// needed -- the ocml rsqrtf wrapper would add scaling code per pair).  fp64: v_rsq_f64 seed
+// (~2^-26) + two Newton-Raphson steps, to stay inside the 1e-10 fp64 gate with margin.
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double rsq(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double hx = 0.5 * x;
+  y = y * __builtin_fma(-hx * y, y, 1.5);
+  y = y * __builtin_fma(-hx * y, y, 1.5);
+  return y;
+}
+
+__device__ __forceinline__ float fmaT(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fmaT(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// One pair: 3 sub, 3 FMA (r^2 + eps^2), 1 rsq, 3 mul (G*m_j * inv^3), 3 FMA (accumulate)
+// = 12 VALU + 1 transcendental = the 20 "algorithmic" flops of DESIGN.md.
+template <typename T>
+__device__ __forceinline__ void pair(T xj, T yj, T zj, T gmj, T xi, T yi, T zi, T& ax, T& ay, T& az) {
+  const T dx = xj - xi, dy = yj - yi, dz = zj - zi;
+  const T r2 = fmaT(dx, dx, fmaT(dy, dy, fmaT(dz, dz, softening2<T>())));
+  const T inv = rsq(r2);
+  const T inv2 = inv * inv;
+  const T s = (gmj * inv) * inv2;
+  ax = fmaT(dx, s, ax);
+  ay = fmaT(dy, s, ay);
+  az = fmaT(dz, s, az);
+}
+
+// Two i-bodies per call on the packed-fp32 pipe (v_pk_add/mul/fma_f32): the j record is a
+// scalar splat (op_sel), the i-bodies live in even-aligned register pairs.  12 packed VALU +
+// 2 v_rsq_f32 per TWO pairs.  A/B'd against the scalar form in tools/kbench.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pair2(float xj, float yj, float zj, float gmj, f32x2 xi, f32x2 yi, f32x2 zi,
+                                      f32x2& ax, f32x2& ay, f32x2& az) {
+  const f32x2 dx = f32x2{xj, xj} - xi, dy = f32x2{yj, yj} - yi, dz = f32x2{zj, zj} - zi;
+  const f32x2 e2 = {softening2<float>(), softening2<float>()};
+  f32x2 r2 = __builtin_elementwise_fma(dz, dz, e2);
+  r2 = __builtin_elementwise_fma(dy, dy, r2);
+  r2 = __builtin_elementwise_fma(dx, dx, r2);
+  f32x2 inv;
+  inv.x = __builtin_amdgcn_rsqf(r2.x);
+  inv.y = __builtin_amdgcn_rsqf(r2.y);
+  const f32x2 inv2 = inv * inv;
+  const f32x2 s = (f32x2{gmj, gmj} * inv) * inv2;
+  ax = __builtin_elementwise_fma(dx, s, ax);
+  ay = __builtin_elementwise_fma(dy, s, ay);
+  az = __builtin_elementwise_fma(dz, s, az);
+}
+
+// Unfused fp32/fp64 multiply-add, so the O(n) update rounds exactly like the reference's
+// x86-64 baseline build (no FMA instruction there).
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+
+// Sum of one double per thread over the 256-thread workgroup, fixed order: wave64 shuffle tree,
+// then the four wave sums through LDS.  Result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double* lds4) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) lds4[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) r = ((lds4[0] + lds4[1]) + lds4[2]) + lds4[3];
+  return r;
+}
+
+// ver7/GSimulation.cpp:181-197 for one body; returns m*(vx^2+vy^2+vz^2) (the reference's term,
+// evaluated in T with the reference's association).
+template <typename T>
+__device__ __forceinline__ T euler_update(T ax, T ay, T az, T dt, typename V4<T>::type& p,
+                                          typename V4<T>::type& v) {
+  v.x = add_rn(v.x, mul_rn(ax, dt));
+  v.y = add_rn(v.y, mul_rn(ay, dt));
+  v.z = add_rn(v.z, mul_rn(az, dt));
+  p.x = add_rn(p.x, mul_rn(v.x, dt));
+  p.y = add_rn(p.y, mul_rn(v.y, dt));
+  p.z = add_rn(p.z, mul_rn(v.z, dt));
+  const T v2 = add_rn(add_rn(mul_rn(v.x, v.x), mul_rn(v.y, v.y)), mul_rn(v.z, v.z));
+  return mul_rn(v.w, v2);
+}
+
+template <typename T>
+struct ForceArgs {
+  const typename V4<T>::type* posm;  // current positions, n_alloc records
+  typename V4<T>::type* accp;        // [gridDim.y][own_pad], written when !FUSED
+  typename V4<T>::type* velm;        // FUSED: owned velocities, updated in place
+  typename V4<T>::type* posm_next;   // FUSED: next position buffer (owned slice written)
+  double* ke_part;                   // FUSED: one partial per workgroup
+  int i_begin, i_count, own_pad;
+  int j_per_split;                   // multiple of kTile; split y covers [y*jps, min((y+1)*jps, n_alloc))
+  int n_alloc;                       // multiple of kTile
+  T dt;
+};
+
+enum : int { JSRC_LDS = 1, JSRC_SGPR = 2 };
+enum : int { MATH_SCALAR = 0, MATH_PACKED = 1 };
+
+// The B i-bodies a lane keeps in registers, and how one j record is applied to them.
+template <typename T, int B, int MATH>
+struct IBodies {
+  T xi[B], yi[B], zi[B], ax[B], ay[B], az[B];
+  __device__ __forceinline__ void set(int b, T x, T y, T z) {
+    xi[b] = x; yi[b] = y; zi[b] = z;
+    ax[b] = ay[b] = az[b] = (T)0;
+  }
+  __device__ __forceinline__ void apply(T xj, T yj, T zj, T gmj) {
+#pragma unroll
+    for (int b = 0; b < B; ++b) pair<T>(xj, yj, zj, gmj, xi[b], yi[b], zi[b], ax[b], ay[b], az[b]);
+  }
+  __device__ __forceinline__ void get(int b, T& x, T& y, T& z) const { x = ax[b]; y = ay[b]; z = az[b]; }
+};
+
+template <int B>
+struct IBodies<float, B, MATH_PACKED> {
+  static_assert(B % 2 == 0, "packed math needs an even number of bodies per lane");
+  f32x2 xi[B / 2], yi[B / 2], zi[B / 2], ax[B / 2], ay[B / 2], az[B / 2];
+  __device__ __forceinline__ void set(int b, float x, float y, float z) {
+    xi[b / 2][b & 1] = x; yi[b / 2][b & 1] = y; zi[b / 2][b & 1] = z;
+    ax[b / 2][b & 1] = 0.f; ay[b / 2][b & 1] = 0.f; az[b / 2][b & 1] = 0.f;
+  }
+  __device__ __forceinline__ void apply(float xj, float yj, float zj, float gmj) {
+#pragma unroll
+    for (int b = 0; b < B / 2; ++b) pair2(xj, yj, zj, gmj, xi[b], yi[b], zi[b], ax[b], ay[b], az[b]);
+  }
+  __device__ __forceinline__ void get(int b, float& x, float& y, float& z) const {
+    x = ax[b / 2][b & 1]; y = ay[b / 2][b & 1]; z = az[b / 2][b & 1];
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// force_kernel: grid (ceil(i_count / (256*B)), S), block 256.
+// Lane t of workgroup bx owns bodies  i_begin + bx*256*B + b*256 + t,  b = 0..B-1  (coalesced).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int B, int JSRC, bool FUSED, int MINW, int MATH = MATH_SCALAR>
+__global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> a) {
+  using T4 = typename V4<T>::type;
+  const int t = threadIdx.x;
+  const int base = blockIdx.x * (kBlock * B) + t;
+
+  IBodies<T, B, MATH> ib;
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    int li = base + b * kBlock;
+    li = li < a.i_count ? li : a.i_count - 1;  // padded lanes shadow the last owned body
+    const T4 p = a.posm[a.i_begin + li];
+    ib.set(b, p.x, p.y, p.z);
+  }
+
+  const int j0 = blockIdx.y * a.j_per_split;
+  int j1 = j0 + a.j_per_split;
+  j1 = j1 < a.n_alloc ? j1 : a.n_alloc;
+
+  if constexpr (JSRC == JSRC_LDS) {
+    __shared__ T4 tile[2][kTile];
+    T4 pre = a.posm[j0 + t];
+    tile[0][t] = pre;
+    __syncthreads();
+    int cur = 0;
+    for (int jt = j0; jt < j1; jt += kTile) {
+      const bool more = jt + kTile < j1;
+      if (more) pre = a.posm[jt + kTile + t];  // in flight under the tile's arithmetic
+      const T4* tl = tile[cur];
+#pragma unroll 8
+      for (int jj = 0; jj < kTile; ++jj) {
+        const T4 pj = tl[jj];  // same address in every lane: broadcast read
+        ib.apply(pj.x, pj.y, pj.z, pj.w);
+      }
+      if (more) tile[cur ^ 1][t] = pre;
+      __syncthreads();  // one barrier per tile: readers of `cur` done, writers of `cur^1` done
+      cur ^= 1;
+    }
+  } else {
+    const T4* __restrict__ pj_ptr = a.posm;
+    constexpr int U = (sizeof(T) == 4) ? 8 : 4;
+    for (int j = j0; j < j1; j += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const T4 pj = pj_ptr[j + u];  // wave-uniform index: s_load into SGPRs
+        ib.apply(pj.x, pj.y, pj.z, pj.w);
+      }
+    }
+  }
+
+  if constexpr (!FUSED) {
+    T4* out = a.accp + (size_t)blockIdx.y * a.own_pad;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const int li = base + b * kBlock;
+      if (li < a.i_count) {
+        T4 r;
+        ib.get(b, r.x, r.y, r.z);
+        r.w = (T)0;
+        out[li] = r;
+      }
+    }
+  } else {
+    __shared__ double ksum[4];
+    double ke = 0.0;
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const int li = base + b * kBlock;
+      if (li < a.i_count) {
+        T4 p = a.posm[a.i_begin + li];
+        T4 v = a.velm[li];
+        T axb, ayb, azb;
+        ib.get(b, axb, ayb, azb);
+        ke += (double)euler_update<T>(axb, ayb, azb, a.dt, p, v);
+        a.velm[li] = v;
+        a.posm_next[a.i_begin + li] = p;
+      }
+    }
+    const double s = block_sum(ke, ksum);
+    if (t == 0) a.ke_part[blockIdx.x] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// integrate_kernel: one body per thread; sums the S partial accelerations in split order.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void integrate_kernel(const typename V4<T>::type* __restrict__ posm_cur,
+                                                           typename V4<T>::type* __restrict__ posm_next,
+                                                           typename V4<T>::type* __restrict__ velm,
+                                                           const typename V4<T>::type* __restrict__ accp,
+                                                           int nsplit, int own_pad, int i_begin, int i_count,
+                                                           T dt, double* __restrict__ ke_part) {
+  using T4 = typename V4<T>::type;
+  __shared__ double ksum[4];
+  const int li = blockIdx.x * kBlock + threadIdx.x;
+  double ke = 0.0;
+  if (li < i_count) {
+    T ax = (T)0, ay = (T)0, az = (T)0;
+    for (int s = 0; s < nsplit; ++s) {
+      const T4 q = accp[(size_t)s * own_pad + li];
+      ax += q.x; ay += q.y; az += q.z;
+    }
+    T4 p = posm_cur[i_begin + li];
+    T4 v = velm[li];
+    ke = (double)euler_update<T>(ax, ay, az, dt, p, v);
+    velm[li] = v;
+    posm_next[i_begin + li] = p;
+  }
+  const double s = block_sum(ke, ksum);
+  if (threadIdx.x == 0) ke_part[blockIdx.x] = s;
+}
+
+// One workgroup; thread t sums partials t, t+256, ... then the block tree: fixed order.
+__global__ __launch_bounds__(kBlock) void ke_reduce_kernel(const double* __restrict__ ke_part, int nparts,
+                                                           double* __restrict__ out) {
+  __shared__ double ksum[4];
+  double v = 0.0;
+  for (int k = threadIdx.x; k < nparts; k += kBlock) v += ke_part[k];
+  const double s = block_sum(v, ksum);
+  if (threadIdx.x == 0) *out = s;
+}
+
+}  // namespace nbx

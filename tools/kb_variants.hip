@@ -1,0 +1,32 @@
+// kb_variants.hip -- compiled twice by tools/Makefile: default flags (KB_NS=nbx_slp) and
+// -fno-slp-vectorize (KB_NS=nbx_noslp), so the compiler's automatic v_pk_* packing can be A/B'd.
+#define nbx KB_NS
+#include "../nbody-demo-2023_amd/csrc/nbx_kernels.hpp"
+#include "kb_common.hpp"
+
+using namespace nbx;
+
+template <int B, int JSRC, int MINW, int MATH>
+static void launch_f32(const KbArgs& k, dim3 grid, hipStream_t st) {
+  ForceArgs<float> a{};
+  a.posm = k.posm; a.accp = k.accp; a.i_begin = 0; a.i_count = k.n; a.own_pad = k.n; a.n_alloc = k.n;
+  a.j_per_split = k.jps;
+  hipLaunchKernelGGL((force_kernel<float, B, JSRC, false, MINW, MATH>), grid, dim3(kBlock), 0, st, a);
+}
+
+#define ADD(B_, J_, W_, S_, M_) \
+  vs.push_back({std::string(KB_TAG) + (J_ == JSRC_LDS ? " lds " : " sgpr") + " B" #B_ " W" #W_ " S" #S_ + (M_ ? " pk" : ""), B_, S_, launch_f32<B_, J_, W_, M_>, {}})
+
+void KB_REGISTER(std::vector<Variant>& vs) {
+  ADD(1, JSRC_LDS, 1, 1, 0);
+  ADD(2, JSRC_LDS, 1, 1, 0);  ADD(2, JSRC_LDS, 1, 2, 0);  ADD(2, JSRC_LDS, 1, 4, 0);
+  ADD(4, JSRC_LDS, 1, 2, 0);  ADD(4, JSRC_LDS, 1, 4, 0);  ADD(4, JSRC_LDS, 1, 8, 0);
+  ADD(8, JSRC_LDS, 1, 4, 0);  ADD(8, JSRC_LDS, 1, 8, 0);  ADD(8, JSRC_LDS, 1, 16, 0);
+  ADD(2, JSRC_SGPR, 1, 2, 0); ADD(2, JSRC_SGPR, 1, 4, 0);
+  ADD(4, JSRC_SGPR, 1, 2, 0); ADD(4, JSRC_SGPR, 1, 4, 0); ADD(4, JSRC_SGPR, 1, 8, 0);
+  ADD(8, JSRC_SGPR, 1, 4, 0); ADD(8, JSRC_SGPR, 1, 8, 0); ADD(8, JSRC_SGPR, 1, 16, 0);
+#ifdef KB_WITH_PK
+  ADD(2, JSRC_LDS, 1, 2, 1);  ADD(4, JSRC_LDS, 1, 4, 1);  ADD(8, JSRC_LDS, 1, 8, 1);
+  ADD(2, JSRC_SGPR, 1, 2, 1); ADD(4, JSRC_SGPR, 1, 4, 1); ADD(8, JSRC_SGPR, 1, 8, 1);
+#endif
+}
