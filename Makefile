@@ -1,0 +1,33 @@
+# Top-level build: libnbx.so (HIP kernels + C-ABI, gfx950 only), the drop-in nbody.x, the oracle.
+HIPCC ?= hipcc
+ARCH  ?= gfx950
+PKG    = nbody-demo-2023_amd
+CSRC   = $(PKG)/csrc
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+
+all: lib host oracle
+
+lib: $(PKG)/libnbx.so
+
+$(PKG)/nbx_api.o: $(CSRC)/nbx_api.hip $(CSRC)/nbx_kernels.hpp include/nbx.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(PKG)/nbx_ic.o: $(CSRC)/nbx_ic.cpp include/nbx.h
+	$(HIPCC) -O2 -std=c++17 -fPIC -Wall -ffp-contract=off -c $< -o $@
+$(PKG)/libnbx.so: $(PKG)/nbx_api.o $(PKG)/nbx_ic.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
+host: lib
+	$(MAKE) -C $(PKG)/host
+
+oracle:
+	$(MAKE) -C oracle
+
+run: host
+	$(PKG)/host/nbody.x
+
+clean:
+	rm -f $(PKG)/*.o $(PKG)/libnbx.so
+	$(MAKE) -C $(PKG)/host clean
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib host oracle run clean

@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's benchmark contract for the GSimulation::start() hot path on MI355X.
+
+A "step" is one time step of ver7/GSimulation.cpp:138-200 over all n bodies: the all-pairs force
+kernel, the Euler update and the kinetic-energy partials (plus, at N > 1, the all-gather of the
+position blocks).  State is resident in HBM before the timed region starts.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload: N == 1 -> BASELINE.json configs[2] (n = 262144, fp32: the roofline configuration the metric's
+target is quoted on); N > 1 -> configs[3] (n = 1048576 block-partitioned over the N ranks, one RCCL
+all-gather of the positions per step).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import statistics
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "nbody-demo-2023_amd")
+for _p in (PKG,):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+PEAK_FP32_VECTOR_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz
+PEAK_FP64_VECTOR_TFLOPS = 78.6
+FLOP_PER_PAIR = 20               # 3 sub + 3 FMA + rsqrt + 3 mul + 3 FMA
+
+
+def usable_cpus():
+    """Threads this job may really use: affinity mask capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, p = open(path).read().split()[:2]
+            if q != "max":
+                n = max(1, min(n, int(float(q) / float(p) + 0.5)))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = max(1, min(n, int(q / p + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(kind, n_gpu, precision):
+    """The reference's CPU path timed on this box's host cores, on a bounded sample.
+
+    kind "reference": oracle/_ref/ver7_trace.x = the reference's unmodified ver7 source compiled in the
+    build container (pinned flags), timing itself with its own CPUTime around both loops, one row per
+    step.  kind "port": the oracle's C restatement (same loops, same flags) called through ctypes.
+    pair/s of this O(n^2) loop does not depend on n beyond cache effects, so the
+    sample uses the largest n <= n_gpu whose few steps fit ~10-30 s of CPU time.
+    """
+    threads = usable_cpus()
+    rate_guess = 0.2e9 * threads  # pair/s, from the survey's 1.7 G pair/s on 8 vCPU
+    n_cpu = n_gpu
+    steps = 3
+    while n_cpu > 16384 and steps * float(n_cpu) ** 2 / rate_guess > 25.0:
+        n_cpu //= 2
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="spread", OMP_PLACES="threads")
+    exe = os.path.join(ROOT, "oracle", "_ref", "ver7_trace.x" if precision == 32 else "ver7_trace_f64.x")
+    under_profiler = any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY"))
+    if kind == "auto":
+        kind = "reference" if (os.path.exists(exe) and not under_profiler) else "port"
+    if kind == "reference":
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "cpu.json")
+            subprocess.run([exe, str(n_cpu), str(steps), out, "1", "1"], env=env, check=True, timeout=600,
+                           stdout=subprocess.DEVNULL)
+            secs = json.load(open(out))["step_seconds"]
+        t = statistics.median(secs[1:]) if len(secs) > 1 else secs[0]
+        what = "reference ver7 (unmodified source, g++ -O2 -fopenmp, built in the build container)"
+    else:
+        for k, v in (("OMP_NUM_THREADS", str(threads)), ("OMP_PROC_BIND", "spread")):
+            os.environ.setdefault(k, v)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import numpy as np
+        import oracle as O
+        s = O.init_state(n_cpu)
+        if precision == 64:
+            s = s.astype(np.float64)
+        secs = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            O.run(s, 1)
+            secs.append(time.perf_counter() - t0)
+        t = statistics.median(secs[1:]) if len(secs) > 1 else secs[0]
+        what = "oracle C restatement of ver7 (gcc -O2 -fopenmp)"
+    return {
+        "value": float(n_cpu) ** 2 / t, "unit": "pair/s", "cores": threads, "kind": kind,
+        "sample": "%s, n=%d, %d steps (first discarded), median step %.3f s, fp%d, OMP_NUM_THREADS=%d"
+                  % (what, n_cpu, steps, t, precision, threads),
+    }
+
+
+def parity_probe(nbx, n, precision):
+    """Cheap in-run check against the reference's golden trace when a fixture exists for this n."""
+    import numpy as np
+    name = {(262144, 32): "ver7_f32_n262144_s7.json", (16384, 32): "ver7_f32_n16384_s500.json",
+            (2000, 32): "ver7_f32_n2000_s500.json"}.get((n, precision))
+    if not name:
+        return None
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", name)))
+    k = min(7, g["nsteps"])
+    with nbx.Context(n, precision) as c:
+        c.upload(nbx.initial_conditions(n, precision))
+        ke = c.step_trace(k)
+    ref = np.array(g["kenergy"][:k])
+    return {"fixture": name, "steps": k, "max_rel_kenergy_err": float((abs(ke - ref) / ref).max())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=0, help="override the body count")
+    ap.add_argument("--precision", type=int, default=32, choices=(32, 64))
+    ap.add_argument("--cpu-baseline", default="auto", choices=("auto", "reference", "port", "none"))
+    ap.add_argument("--bodies-per-lane", type=int, default=0)
+    ap.add_argument("--j-split", type=int, default=0)
+    ap.add_argument("--kernel", default="auto", choices=("auto", "lds", "sgpr"))
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+    n = a.n or (262144 if a.gpus == 1 else 1048576)
+    workload = ("BASELINE.json configs[2]: 1xMI355X nPart=262144 fp32" if (n == 262144 and a.gpus == 1) else
+                "BASELINE.json configs[3]: nPart=1048576 block-partitioned, all-gather(pos) per step" if n == 1048576 else
+                "nPart=%d" % n)
+
+    # CPU baseline first: it may start a child process, so it runs before this process touches the GPU
+    cpu = None
+    if a.gpus == 1 and rank == 0 and a.cpu_baseline != "none":
+        cpu = cpu_baseline(a.cpu_baseline, n, a.precision)
+
+    import torch
+    import torch.distributed as dist
+    import nbx
+    import sharded
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    opts = dict(bodies_per_lane=a.bodies_per_lane, j_split=a.j_split,
+                kernel_variant={"auto": 0, "lds": 1, "sgpr": 2}[a.kernel])
+
+    parity = parity_probe(nbx, n, a.precision) if (rank == 0 and world == 1) else None
+
+    ic = nbx.initial_conditions(n, a.precision)  # synthetic: the reference's seed-42 generator
+    sim = sharded.ShardedSimulation(n, a.precision, dist=dist if world > 1 else None, **opts)
+    sim.upload(ic)
+
+    def fence():
+        sim.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sim.step(a.warmup)
+    fence()
+    sim.engine.ctx.profile(True)  # HIP events around every force launch, on the context's own stream
+    t0 = time.perf_counter()
+    sim.step(a.steps)
+    fence()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = sim.engine.ctx.stats()
+    ke = sim.kenergy()
+
+    if rank == 0:
+        pairs_per_step = float(n) * float(n)
+        value = pairs_per_step * a.steps / elapsed
+        peak = PEAK_FP32_VECTOR_TFLOPS if a.precision == 32 else PEAK_FP64_VECTOR_TFLOPS
+        launch_ms = st["force_ms_total"] / max(1, st["force_launches_timed"])
+        achieved = FLOP_PER_PAIR * st["pairs_per_launch"] / (launch_ms * 1e-3) * 1e-12 if launch_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("n") == n and tj.get("gpus", 1) == a.gpus:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "pair-interactions/s", "value": value, "unit": "pair/s", "n_gpus": a.gpus,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "strong" if a.gpus > 1 else "weak", "vs_baseline": None,
+            "dtype": "f32" if a.precision == 32 else "f64", "data": "synthetic",
+            "config": {"workload": workload, "n_bodies": n, "bodies_per_gpu": st["i_count"],
+                       "parallelism": "i-block x%d" % a.gpus, "j_tile": st["j_tile"],
+                       "bodies_per_lane": st["bodies_per_lane"], "j_split": st["j_split"],
+                       "kernel": {1: "lds", 2: "sgpr"}.get(st["kernel_variant"], "?"),
+                       "grid": [st["force_grid_x"], st["force_grid_y"]], "block": st["force_block"]},
+            "gflops_reference_convention": 1e-9 * (29.0 * pairs_per_step + 19.0 * n) * a.steps / elapsed,
+            "kenergy_after_run": ke,
+            "roofline": {"bound": "valu", "kernel": "nbx::force_kernel", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": st["pairs_per_launch"],
+                         "launch_ms_avg": launch_ms, "launches_timed": st["force_launches_timed"],
+                         "note": "fp32 vector FMA roofline (north_star: FMA/rsqrt-bound, no MFMA); 157.3 TFLOP/s is "
+                                 "also the dense f32 MFMA peak.  HBM is not the bound: see DESIGN.md"},
+            "device": st["device_name"], "cu_count": st["cu_count"],
+        }
+        if parity:
+            line["parity"] = parity
+        if cpu:
+            line["cpu_baseline"] = cpu
+            line["gpu_over_cpu"] = value / cpu["value"]
+        print(json.dumps(line), flush=True)
+
+    sim.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

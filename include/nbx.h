@@ -62,9 +62,9 @@ typedef struct nbx_opts {
   int32_t bodies_per_lane; /* register blocking of i-bodies: 1,2,4,8; 0 = auto */
   int32_t j_split;         /* workgroups sharing one i-block, each summing a j-range; 0 = auto */
   int32_t kernel_variant;  /* NBX_KERNEL_* */
-  int32_t fused_epilogue;  /* 1: integrate in the force kernel when j_split==1; 0: separate kernel;
-                              -1/unset(0 with struct_size==0) = auto */
-  int32_t use_graph;       /* 1: replay multi-step windows from a hipGraph; 0: plain launches */
+  int32_t fused_epilogue;  /* 0 = auto (fused when j_split == 1), 1 = on where possible, 2 = off
+                              (always the separate integrate kernel) */
+  int32_t use_graph;       /* 0 = auto, 1 = replay multi-step windows from a hipGraph, 2 = plain launches */
   int32_t reserved[5];
 } nbx_opts;
 
@@ -144,6 +144,17 @@ int nbx_sync(nbx_ctx* ctx);
  */
 int nbx_download(nbx_ctx* ctx, void* pos_x, void* pos_y, void* pos_z, void* vel_x, void* vel_y,
                  void* vel_z);
+
+/*
+ * Seed-42 initial conditions of ver7/GSimulation.cpp:45-94, bit-exact and independent of the
+ * host's libstdc++: mt19937(42) re-created per array family, libstdc++-11's
+ * uniform_real_distribution<float> restated (one 32-bit draw per value).  Host-only (no GPU
+ * needed).  precision 32 writes float arrays; 64 writes the SAME fp32-drawn values widened to
+ * double (SURVEY.md 8c variant B).  Arrays hold n elements.
+ */
+int nbx_ic_pos(int32_t n, int32_t precision, void* pos_x, void* pos_y, void* pos_z);
+int nbx_ic_vel(int32_t n, int32_t precision, void* vel_x, void* vel_y, void* vel_z);
+int nbx_ic_mass(int32_t n, int32_t precision, void* mass);
 
 /* Per-launch HIP-event timing of the force kernel (on the context's stream). */
 int nbx_profile(nbx_ctx* ctx, int32_t enable);

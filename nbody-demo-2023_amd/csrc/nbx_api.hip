@@ -1,0 +1,604 @@
+// nbx_api.hip -- the C-ABI of include/nbx.h over the gfx950 kernels of nbx_kernels.hpp.
+//
+// One context = one GPU's share of the reference's GSimulation::start() loop
+// (ver7/GSimulation.cpp:138-200): it owns bodies [i_begin, i_begin+i_count), keeps
+// {x,y,z,G*m} of ALL bodies resident (double buffered) and {vx,vy,vz,m} of its own.
+// No CPU fallback exists: without a HIP device every entry point fails with NBX_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/nbx.h"
+#include "nbx_kernels.hpp"
+
+using namespace nbx;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(NBX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+constexpr int kMaxProfiledLaunches = 8192;
+
+}  // namespace
+
+struct nbx_ctx {
+  int n = 0, n_alloc = 0, i_begin = 0, i_count = 0, own_pad = 0, precision = 32;
+  int B = 1, S = 1, jps = 0, variant = NBX_KERNEL_LDS, fused = 0, math = MATH_SCALAR;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  size_t rec = 16;  // bytes per {x,y,z,w} record
+  void* posm[2] = {nullptr, nullptr};
+  int cur = 0;
+  void* velm = nullptr;
+  void* accp = nullptr;
+  double* ke_part = nullptr;
+  int ke_parts = 0;       // partials written by the last step
+  double* ke_dev = nullptr;  // [ke_cap] reduced sums (sum m v^2)
+  int ke_cap = 0;
+  bool uploaded = false;
+  bool pending_commit = false;
+  long long steps_done = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;  // pairs start/stop
+  size_t ev_used = 0;
+  double force_ms_total = 0.0;
+  long long force_timed = 0;
+  hipDeviceProp_t prop{};
+  dim3 grid;
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// kernel dispatch
+// ------------------------------------------------------------------------------------------
+template <typename T, int B, int JSRC, bool FUSED, int MATH>
+void launch_force_t(const ForceArgs<T>& a, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((force_kernel<T, B, JSRC, FUSED, 1, MATH>), grid, dim3(kBlock), 0, st, a);
+}
+
+template <typename T>
+using ForceLauncher = void (*)(const ForceArgs<T>&, dim3, hipStream_t);
+
+template <typename T, int JSRC, bool FUSED, int MATH>
+ForceLauncher<T> pick_b(int B) {
+  switch (B) {
+    case 1:
+      if constexpr (MATH == MATH_SCALAR) return launch_force_t<T, 1, JSRC, FUSED, MATH>;
+      return nullptr;
+    case 2: return launch_force_t<T, 2, JSRC, FUSED, MATH>;
+    case 4: return launch_force_t<T, 4, JSRC, FUSED, MATH>;
+    case 8:
+      if constexpr (sizeof(T) == 4) return launch_force_t<T, 8, JSRC, FUSED, MATH>;
+      return nullptr;
+  }
+  return nullptr;
+}
+
+template <typename T, int MATH>
+ForceLauncher<T> pick(int B, int variant, bool fused) {
+  if (variant == NBX_KERNEL_SGPR)
+    return fused ? pick_b<T, JSRC_SGPR, true, MATH>(B) : pick_b<T, JSRC_SGPR, false, MATH>(B);
+  return fused ? pick_b<T, JSRC_LDS, true, MATH>(B) : pick_b<T, JSRC_LDS, false, MATH>(B);
+}
+
+template <typename T>
+ForceLauncher<T> pick_force(const nbx_ctx* c, bool fused) {
+  if constexpr (sizeof(T) == 4) {
+    if (c->math == MATH_PACKED) return pick<float, MATH_PACKED>(c->B, c->variant, fused);
+  }
+  return pick<T, MATH_SCALAR>(c->B, c->variant, fused);
+}
+
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// Choose register blocking B and j-split S so the launch has enough waves to fill 256 CUs
+// (measured with tools/kbench on MI355X; see DESIGN.md "launch shape").
+void auto_shape(nbx_ctx* c, const nbx_opts& o) {
+  const int cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+  const int target_wgs = cus * 4;  // 4 workgroups (16 waves) per CU
+  const int max_split = std::max(1, c->n_alloc / kTile);
+  const int maxB = c->precision == 32 ? 8 : 4;
+  int B = o.bodies_per_lane;
+  if (B != 1 && B != 2 && B != 4 && B != 8) B = 0;
+  if (B > maxB) B = maxB;
+  if (B == 0) {
+    B = maxB;
+    // shrink B while even the deepest useful split cannot reach the target
+    while (B > 2 && (long long)ceil_div(c->i_count, kBlock * B) * std::min(max_split, 64) < target_wgs) B /= 2;
+  }
+  int S = o.j_split;
+  if (S <= 0) {
+    const int bi = ceil_div(c->i_count, kBlock * B);
+    S = ceil_div(target_wgs, bi);
+  }
+  S = std::max(1, std::min(S, max_split));
+  int jps = round_up(ceil_div(c->n_alloc, S), kTile);
+  S = ceil_div(c->n_alloc, jps);  // drop empty tail splits
+  c->B = B;
+  c->S = S;
+  c->jps = jps;
+  c->math = (c->precision == 32 && B >= 2) ? MATH_PACKED : MATH_SCALAR;
+  c->variant = o.kernel_variant == NBX_KERNEL_SGPR ? NBX_KERNEL_SGPR : NBX_KERNEL_LDS;
+  // fused_epilogue: 0 auto, 1 on, 2 off; only possible without a j-split
+  c->fused = (S == 1 && o.fused_epilogue != 2) ? 1 : 0;
+  c->grid = dim3(ceil_div(c->i_count, kBlock * B), S);
+}
+
+template <typename T>
+int enqueue_force(nbx_ctx* c, bool fused, double dt) {
+  ForceLauncher<T> fn = pick_force<T>(c, fused);
+  if (!fn) return fail(NBX_ERR_ARG, "no kernel instance for this bodies_per_lane / precision");
+  ForceArgs<T> a{};
+  using T4 = typename V4<T>::type;
+  a.posm = (const T4*)c->posm[c->cur];
+  a.accp = (T4*)c->accp;
+  a.velm = (T4*)c->velm;
+  a.posm_next = (T4*)c->posm[c->cur ^ 1];
+  a.ke_part = c->ke_part;
+  a.i_begin = c->i_begin;
+  a.i_count = c->i_count;
+  a.own_pad = c->own_pad;
+  a.j_per_split = c->jps;
+  a.n_alloc = c->n_alloc;
+  a.dt = (T)dt;
+  const bool prof = c->profiling && c->ev_used + 2 <= c->ev.size();
+  if (prof) HIP_TRY(hipEventRecord(c->ev[c->ev_used], c->stream));
+  fn(a, c->grid, c->stream);
+  if (prof) {
+    HIP_TRY(hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+    c->ev_used += 2;
+  }
+  HIP_TRY(hipGetLastError());
+  return NBX_OK;
+}
+
+// one local step: force (+ integrate) into the next buffer; does not swap
+template <typename T>
+int enqueue_step(nbx_ctx* c, double dt) {
+  using T4 = typename V4<T>::type;
+  int rc = enqueue_force<T>(c, c->fused != 0, dt);
+  if (rc) return rc;
+  if (c->fused) {
+    c->ke_parts = c->grid.x;
+  } else {
+    const int blocks = ceil_div(c->i_count, kBlock);
+    hipLaunchKernelGGL((integrate_kernel<T>), dim3(blocks), dim3(kBlock), 0, c->stream,
+                       (const T4*)c->posm[c->cur], (T4*)c->posm[c->cur ^ 1], (T4*)c->velm,
+                       (const T4*)c->accp, c->S, c->own_pad, c->i_begin, c->i_count, (T)dt, c->ke_part);
+    HIP_TRY(hipGetLastError());
+    c->ke_parts = blocks;
+  }
+  return NBX_OK;
+}
+
+int enqueue_step_any(nbx_ctx* c, double dt) {
+  return c->precision == 32 ? enqueue_step<float>(c, dt) : enqueue_step<double>(c, dt);
+}
+
+int ensure_ke_cap(nbx_ctx* c, int need) {
+  if (need <= c->ke_cap) return NBX_OK;
+  if (c->ke_dev) HIP_TRY(hipFree(c->ke_dev));
+  c->ke_dev = nullptr;
+  c->ke_cap = 0;
+  HIP_TRY(hipMalloc(&c->ke_dev, sizeof(double) * (size_t)need));
+  c->ke_cap = need;
+  return NBX_OK;
+}
+
+int enqueue_ke_reduce(nbx_ctx* c, int slot) {
+  hipLaunchKernelGGL(ke_reduce_kernel, dim3(1), dim3(kBlock), 0, c->stream, (const double*)c->ke_part,
+                     c->ke_parts, c->ke_dev + slot);
+  HIP_TRY(hipGetLastError());
+  return NBX_OK;
+}
+
+int drain_profile(nbx_ctx* c) {
+  for (size_t k = 0; k + 1 < c->ev_used; k += 2) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]));
+    c->force_ms_total += ms;
+    c->force_timed += 1;
+  }
+  c->ev_used = 0;
+  return NBX_OK;
+}
+
+int use_device(nbx_ctx* c) {
+  HIP_TRY(hipSetDevice(c->device));
+  return NBX_OK;
+}
+
+template <typename T>
+int upload_t(nbx_ctx* c, const T* px, const T* py, const T* pz, const T* vx, const T* vy, const T* vz,
+             const T* m) {
+  using T4 = typename V4<T>::type;
+  std::vector<T4> hp((size_t)c->n_alloc);
+  const T G = grav_const<T>();
+  for (int i = 0; i < c->n; ++i) {
+    T4 r; r.x = px[i]; r.y = py[i]; r.z = pz[i]; r.w = G * m[i];
+    hp[i] = r;
+  }
+  for (int i = c->n; i < c->n_alloc; ++i) { T4 z; z.x = z.y = z.z = z.w = (T)0; hp[i] = z; }
+  std::vector<T4> hv((size_t)c->own_pad);
+  for (int k = 0; k < c->own_pad; ++k) {
+    T4 r; r.x = r.y = r.z = r.w = (T)0;
+    if (k < c->i_count) { const int i = c->i_begin + k; r.x = vx[i]; r.y = vy[i]; r.z = vz[i]; r.w = m[i]; }
+    hv[k] = r;
+  }
+  HIP_TRY(hipMemcpyAsync(c->posm[0], hp.data(), sizeof(T4) * hp.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->posm[1], hp.data(), sizeof(T4) * hp.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->velm, hv.data(), sizeof(T4) * hv.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return NBX_OK;
+}
+
+template <typename T>
+int download_t(nbx_ctx* c, T* px, T* py, T* pz, T* vx, T* vy, T* vz) {
+  using T4 = typename V4<T>::type;
+  if (px || py || pz) {
+    std::vector<T4> hp((size_t)c->n);
+    HIP_TRY(hipMemcpyAsync(hp.data(), c->posm[c->cur], sizeof(T4) * hp.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->n; ++i) {
+      if (px) px[i] = hp[i].x;
+      if (py) py[i] = hp[i].y;
+      if (pz) pz[i] = hp[i].z;
+    }
+  }
+  if (vx || vy || vz) {
+    std::vector<T4> hv((size_t)c->i_count);
+    HIP_TRY(hipMemcpyAsync(hv.data(), c->velm, sizeof(T4) * hv.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < c->i_count; ++k) {
+      const int i = c->i_begin + k;
+      if (vx) vx[i] = hv[k].x;
+      if (vy) vy[i] = hv[k].y;
+      if (vz) vz[i] = hv[k].z;
+    }
+  }
+  return NBX_OK;
+}
+
+template <typename T>
+int accel_t(nbx_ctx* c, T* ax, T* ay, T* az) {
+  using T4 = typename V4<T>::type;
+  int rc = enqueue_force<T>(c, false, 0.0);
+  if (rc) return rc;
+  std::vector<T4> h((size_t)c->S * c->own_pad);
+  HIP_TRY(hipMemcpyAsync(h.data(), c->accp, sizeof(T4) * h.size(), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < c->i_count; ++k) {
+    T sx = (T)0, sy = (T)0, sz = (T)0;
+    for (int s = 0; s < c->S; ++s) {  // same order as integrate_kernel
+      const T4& q = h[(size_t)s * c->own_pad + k];
+      sx += q.x; sy += q.y; sz += q.z;
+    }
+    const int i = c->i_begin + k;
+    if (ax) ax[i] = sx;
+    if (ay) ay[i] = sy;
+    if (az) az[i] = sz;
+  }
+  return NBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nbx_last_error(void) { return g_err.c_str(); }
+int32_t nbx_abi_version(void) { return NBX_ABI_VERSION; }
+
+int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts) {
+  if (!out) return fail(NBX_ERR_ARG, "nbx_create: out is NULL");
+  *out = nullptr;
+  if (n <= 0) return fail(NBX_ERR_ARG, "nbx_create: n must be > 0");
+  if (precision != 32 && precision != 64) return fail(NBX_ERR_ARG, "nbx_create: precision must be 32 or 64");
+  nbx_opts o;
+  std::memset(&o, 0, sizeof(o));
+  o.device = -1;
+  if (opts) {
+    if (opts->struct_size != 0 && opts->struct_size != (int32_t)sizeof(nbx_opts))
+      return fail(NBX_ERR_ARG, "nbx_create: nbx_opts.struct_size does not match this library");
+    o = *opts;
+  }
+  if (o.i_begin < 0 || o.i_count < 0 || o.i_begin >= n || (long long)o.i_begin + o.i_count > n)
+    return fail(NBX_ERR_ARG, "nbx_create: slice [i_begin, i_begin+i_count) is outside [0, n)");
+  if (o.n_alloc != 0 && o.n_alloc < n) return fail(NBX_ERR_ARG, "nbx_create: n_alloc < n");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(NBX_ERR_DEVICE, "nbx_create: no HIP device available (libnbx has no CPU path)");
+  int dev = o.device;
+  if (dev < 0) {
+    if (hipGetDevice(&dev) != hipSuccess) return fail(NBX_ERR_DEVICE, "nbx_create: hipGetDevice failed");
+  }
+  if (dev >= ndev) return fail(NBX_ERR_ARG, "nbx_create: device ordinal out of range");
+
+  nbx_ctx* c = new (std::nothrow) nbx_ctx();
+  if (!c) return fail(NBX_ERR_ALLOC, "nbx_create: out of host memory");
+  c->device = dev;
+  c->n = n;
+  c->precision = precision;
+  c->rec = precision == 32 ? sizeof(float4) : sizeof(double4);
+  c->i_begin = o.i_begin;
+  c->i_count = o.i_count == 0 ? n - o.i_begin : o.i_count;
+  if (o.i_count == 0 && o.i_begin != 0) c->i_count = n - o.i_begin;
+  c->n_alloc = round_up(std::max(n, o.n_alloc), kTile);
+  c->own_pad = round_up(c->i_count, kBlock);
+
+#define CREATE_TRY(expr)                                                                 \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      std::string m_ = std::string("nbx_create: " #expr ": ") + hipGetErrorString(e_);   \
+      nbx_destroy(c);                                                                    \
+      return fail(e_ == hipErrorOutOfMemory ? NBX_ERR_ALLOC : NBX_ERR_DEVICE, m_);       \
+    }                                                                                    \
+  } while (0)
+
+  CREATE_TRY(hipSetDevice(dev));
+  CREATE_TRY(hipGetDeviceProperties(&c->prop, dev));
+  if (o.stream) {
+    c->stream = (hipStream_t)o.stream;
+  } else {
+    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  auto_shape(c, o);
+  if (o.use_graph) { /* reserved: windows are enqueued as plain launches in this version */ }
+
+  const size_t pos_bytes = c->rec * (size_t)c->n_alloc;
+  CREATE_TRY(hipMalloc(&c->posm[0], pos_bytes));
+  CREATE_TRY(hipMalloc(&c->posm[1], pos_bytes));
+  CREATE_TRY(hipMalloc(&c->velm, c->rec * (size_t)c->own_pad));
+  CREATE_TRY(hipMalloc(&c->accp, c->rec * (size_t)c->own_pad * c->S));
+  const int max_parts = std::max(ceil_div(c->i_count, kBlock), (int)c->grid.x);
+  CREATE_TRY(hipMalloc(&c->ke_part, sizeof(double) * (size_t)max_parts));
+  CREATE_TRY(hipMemsetAsync(c->posm[0], 0, pos_bytes, c->stream));
+  CREATE_TRY(hipMemsetAsync(c->posm[1], 0, pos_bytes, c->stream));
+  CREATE_TRY(hipMemsetAsync(c->ke_part, 0, sizeof(double) * (size_t)max_parts, c->stream));
+  CREATE_TRY(hipStreamSynchronize(c->stream));
+#undef CREATE_TRY
+  if (ensure_ke_cap(c, 64) != NBX_OK) {
+    std::string m = g_err;
+    nbx_destroy(c);
+    return fail(NBX_ERR_ALLOC, m);
+  }
+  *out = c;
+  g_err.clear();
+  return NBX_OK;
+}
+
+void nbx_destroy(nbx_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  if (c->posm[0]) (void)hipFree(c->posm[0]);
+  if (c->posm[1]) (void)hipFree(c->posm[1]);
+  if (c->velm) (void)hipFree(c->velm);
+  if (c->accp) (void)hipFree(c->accp);
+  if (c->ke_part) (void)hipFree(c->ke_part);
+  if (c->ke_dev) (void)hipFree(c->ke_dev);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int nbx_upload(nbx_ctx* c, const void* px, const void* py, const void* pz, const void* vx, const void* vy,
+               const void* vz, const void* m) {
+  if (!c) return fail(NBX_ERR_ARG, "nbx_upload: ctx is NULL");
+  if (!px || !py || !pz || !vx || !vy || !vz || !m) return fail(NBX_ERR_ARG, "nbx_upload: NULL array");
+  int rc = use_device(c);
+  if (rc) return rc;
+  rc = c->precision == 32
+           ? upload_t<float>(c, (const float*)px, (const float*)py, (const float*)pz, (const float*)vx,
+                             (const float*)vy, (const float*)vz, (const float*)m)
+           : upload_t<double>(c, (const double*)px, (const double*)py, (const double*)pz, (const double*)vx,
+                              (const double*)vy, (const double*)vz, (const double*)m);
+  if (rc) return rc;
+  c->cur = 0;
+  c->uploaded = true;
+  c->pending_commit = false;
+  return NBX_OK;
+}
+
+static int step_common(nbx_ctx* c, double dt, int32_t nsteps, double* ke_last, double* ke_trace) {
+  if (!c) return fail(NBX_ERR_ARG, "nbx_step: ctx is NULL");
+  if (nsteps < 0) return fail(NBX_ERR_ARG, "nbx_step: nsteps < 0");
+  if (!c->uploaded) return fail(NBX_ERR_STATE, "nbx_step: nbx_upload has not been called");
+  if (c->i_begin != 0 || c->i_count != c->n)
+    return fail(NBX_ERR_STATE, "nbx_step: context owns a slice; use nbx_step_local + exchange + nbx_commit");
+  if (c->pending_commit) return fail(NBX_ERR_STATE, "nbx_step: a local step awaits nbx_commit");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (ke_trace) {
+    rc = ensure_ke_cap(c, std::max(nsteps, 1));
+    if (rc) return rc;
+  }
+  for (int s = 0; s < nsteps; ++s) {
+    rc = enqueue_step_any(c, dt);
+    if (rc) return rc;
+    c->cur ^= 1;
+    c->steps_done += 1;
+    if (ke_trace) {
+      rc = enqueue_ke_reduce(c, s);
+      if (rc) return rc;
+    } else if (ke_last && s == nsteps - 1) {
+      rc = enqueue_ke_reduce(c, 0);
+      if (rc) return rc;
+    }
+  }
+  if (ke_trace && nsteps > 0) {
+    HIP_TRY(hipMemcpyAsync(ke_trace, c->ke_dev, sizeof(double) * (size_t)nsteps, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int s = 0; s < nsteps; ++s) ke_trace[s] *= 0.5;  // ver7/GSimulation.cpp:200
+  } else if (ke_last) {
+    if (nsteps > 0 || c->ke_parts > 0) {
+      if (nsteps == 0) {
+        rc = enqueue_ke_reduce(c, 0);
+        if (rc) return rc;
+      }
+      double sum = 0.0;
+      HIP_TRY(hipMemcpyAsync(&sum, c->ke_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      *ke_last = 0.5 * sum;
+    } else {
+      *ke_last = 0.0;
+    }
+  }
+  return NBX_OK;
+}
+
+int nbx_step(nbx_ctx* c, double dt, int32_t nsteps, double* kenergy_out) {
+  return step_common(c, dt, nsteps, kenergy_out, nullptr);
+}
+
+int nbx_step_trace(nbx_ctx* c, double dt, int32_t nsteps, double* ke_trace) {
+  if (!ke_trace) return fail(NBX_ERR_ARG, "nbx_step_trace: ke_trace is NULL");
+  return step_common(c, dt, nsteps, nullptr, ke_trace);
+}
+
+int nbx_step_local(nbx_ctx* c, double dt) {
+  if (!c) return fail(NBX_ERR_ARG, "nbx_step_local: ctx is NULL");
+  if (!c->uploaded) return fail(NBX_ERR_STATE, "nbx_step_local: nbx_upload has not been called");
+  if (c->pending_commit) return fail(NBX_ERR_STATE, "nbx_step_local: previous step not committed");
+  int rc = use_device(c);
+  if (rc) return rc;
+  rc = enqueue_step_any(c, dt);
+  if (rc) return rc;
+  c->pending_commit = true;
+  return NBX_OK;
+}
+
+int nbx_exchange_buffer(nbx_ctx* c, void** dev_ptr, size_t* total_bytes, size_t* own_offset_bytes, size_t* own_bytes) {
+  if (!c || !dev_ptr) return fail(NBX_ERR_ARG, "nbx_exchange_buffer: NULL argument");
+  // the buffer the last local step wrote (NEXT while a commit is pending, else current)
+  *dev_ptr = c->posm[c->pending_commit ? (c->cur ^ 1) : c->cur];
+  if (total_bytes) *total_bytes = c->rec * (size_t)c->n_alloc;
+  if (own_offset_bytes) *own_offset_bytes = c->rec * (size_t)c->i_begin;
+  if (own_bytes) *own_bytes = c->rec * (size_t)c->i_count;
+  return NBX_OK;
+}
+
+int nbx_commit(nbx_ctx* c) {
+  if (!c) return fail(NBX_ERR_ARG, "nbx_commit: ctx is NULL");
+  if (!c->pending_commit) return fail(NBX_ERR_STATE, "nbx_commit: no local step pending");
+  c->cur ^= 1;
+  c->pending_commit = false;
+  c->steps_done += 1;
+  return NBX_OK;
+}
+
+int nbx_kenergy_partial(nbx_ctx* c, double* sum_mv2) {
+  if (!c || !sum_mv2) return fail(NBX_ERR_ARG, "nbx_kenergy_partial: NULL argument");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (c->ke_parts <= 0) {
+    *sum_mv2 = 0.0;
+    return NBX_OK;
+  }
+  rc = enqueue_ke_reduce(c, 0);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(sum_mv2, c->ke_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return NBX_OK;
+}
+
+int nbx_accel(nbx_ctx* c, void* ax, void* ay, void* az) {
+  if (!c) return fail(NBX_ERR_ARG, "nbx_accel: ctx is NULL");
+  if (!c->uploaded) return fail(NBX_ERR_STATE, "nbx_accel: nbx_upload has not been called");
+  if (c->pending_commit) return fail(NBX_ERR_STATE, "nbx_accel: a local step awaits nbx_commit");
+  int rc = use_device(c);
+  if (rc) return rc;
+  return c->precision == 32 ? accel_t<float>(c, (float*)ax, (float*)ay, (float*)az)
+                            : accel_t<double>(c, (double*)ax, (double*)ay, (double*)az);
+}
+
+int nbx_sync(nbx_ctx* c) {
+  if (!c) return fail(NBX_ERR_ARG, "nbx_sync: ctx is NULL");
+  int rc = use_device(c);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return NBX_OK;
+}
+
+int nbx_download(nbx_ctx* c, void* px, void* py, void* pz, void* vx, void* vy, void* vz) {
+  if (!c) return fail(NBX_ERR_ARG, "nbx_download: ctx is NULL");
+  if (!c->uploaded) return fail(NBX_ERR_STATE, "nbx_download: nbx_upload has not been called");
+  int rc = use_device(c);
+  if (rc) return rc;
+  return c->precision == 32
+             ? download_t<float>(c, (float*)px, (float*)py, (float*)pz, (float*)vx, (float*)vy, (float*)vz)
+             : download_t<double>(c, (double*)px, (double*)py, (double*)pz, (double*)vx, (double*)vy, (double*)vz);
+}
+
+int nbx_profile(nbx_ctx* c, int32_t enable) {
+  if (!c) return fail(NBX_ERR_ARG, "nbx_profile: ctx is NULL");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (enable && c->ev.empty()) {
+    c->ev.resize(2 * kMaxProfiledLaunches);
+    for (auto& e : c->ev) e = nullptr;
+    for (auto& e : c->ev) HIP_TRY(hipEventCreate(&e));
+  }
+  if (!enable && c->profiling) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = drain_profile(c);
+    if (rc) return rc;
+  }
+  if (enable && !c->profiling) {
+    c->force_ms_total = 0.0;
+    c->force_timed = 0;
+    c->ev_used = 0;
+  }
+  c->profiling = enable != 0;
+  return NBX_OK;
+}
+
+int nbx_stats(nbx_ctx* c, nbx_stats_t* s) {
+  if (!c || !s) return fail(NBX_ERR_ARG, "nbx_stats: NULL argument");
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (c->ev_used) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = drain_profile(c);
+    if (rc) return rc;
+  }
+  std::memset(s, 0, sizeof(*s));
+  s->n = c->n; s->n_alloc = c->n_alloc; s->i_begin = c->i_begin; s->i_count = c->i_count;
+  s->precision = c->precision; s->bodies_per_lane = c->B; s->j_split = c->S; s->j_tile = kTile;
+  s->kernel_variant = c->variant; s->fused_epilogue = c->fused;
+  s->force_grid_x = c->grid.x; s->force_grid_y = c->grid.y; s->force_block = kBlock;
+  s->cu_count = c->prop.multiProcessorCount; s->clock_mhz = c->prop.clockRate / 1000;
+  s->steps_done = c->steps_done;
+  s->force_launches_timed = c->force_timed;
+  s->force_ms_total = c->force_ms_total;
+  s->pairs_per_launch = (double)c->i_count * (double)c->n;
+  // some boxes report an empty marketing name; fall back to / append the ISA name
+  std::snprintf(s->device_name, sizeof(s->device_name), "%s%s%s", c->prop.name, c->prop.name[0] ? " " : "",
+                c->prop.gcnArchName);
+  return NBX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,81 @@
+// GSimulation.hpp -- host mirror of the reference's simulation object.
+//
+// Same public surface as ver7/GSimulation.hpp:36-80 (ctor, dtor, init(),
+// set_number_of_particles, set_number_of_steps, start()) plus the ver5_all knobs
+// (ver5_all/GSimulation.hpp:51-58) so either main() links against it.  What differs is
+// below start(): the per-step loops run on the MI355X through the C-ABI of include/nbx.h
+// instead of OpenMP loops; allocation, initial conditions, timing and printing stay here.
+#ifndef NBX_HOST_GSIMULATION_HPP
+#define NBX_HOST_GSIMULATION_HPP
+
+#include <string>
+
+#include "Particle.hpp"
+
+struct nbx_ctx;
+
+class GSimulation {
+ public:
+  GSimulation();
+  ~GSimulation();
+
+  void init();  // declared but never defined in the reference (ver7/GSimulation.hpp:42); here:
+                // allocate the particle store and draw the seed-42 initial conditions
+  void set_number_of_particles(int N);
+  void set_number_of_steps(int N);
+  void start();
+
+  // ver5_all/GSimulation.hpp:51-58 -- accepted for CLI compatibility
+  void set_cpu_ratio(const float& r) { _cpu_ratio = r; }
+  void set_thread_dim0(const int& d) { _thread_dim0 = d; }
+  void set_thread_dim1(const int& d) { _thread_dim1 = d; }
+  int get_thread_dim0() { return _thread_dim0; }
+  int get_thread_dim1() { return _thread_dim1; }
+  int get_cpu_ratio() const { return (int)_cpu_ratio; }
+  void set_devices(int N) { _devices = N; }
+  int get_devices() { return _devices; }
+
+  // read-only views for embedding code and tests (the reference keeps these private)
+  const ParticleSoA* particle_store() const { return particles; }
+  real_type kinetic_energy() const { return _kenergy; }
+  double total_time() const { return _totTime; }
+  double total_flops() const { return _totFlops; }
+
+ private:
+  ParticleSoA* particles;
+
+  int _npart;        // number of particles
+  int _nsteps;       // number of integration steps
+  real_type _tstep;  // time step
+  int _sfreq;        // sample (print) frequency
+  real_type _kenergy;
+  double _totTime;
+  double _totFlops;
+
+  float _cpu_ratio;
+  int _thread_dim0, _thread_dim1, _devices;
+
+  bool _allocated;
+  int _alloc_n;
+
+  void allocate_store(int n);
+  void release_store();
+
+  void init_pos();
+  void init_vel();
+  void init_acc();
+  void init_mass();
+
+  void set_npart(const int& N) { _npart = N; }
+  int get_npart() const { return _npart; }
+  void set_tstep(const real_type& dt) { _tstep = dt; }
+  real_type get_tstep() const { return _tstep; }
+  void set_nsteps(const int& n) { _nsteps = n; }
+  int get_nsteps() const { return _nsteps; }
+  void set_sfreq(const int& sf) { _sfreq = sf; }
+  int get_sfreq() const { return _sfreq; }
+
+  void print_header();
+};
+
+#endif

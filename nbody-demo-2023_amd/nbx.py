@@ -1,0 +1,231 @@
+"""ctypes binding of libnbx.so (include/nbx.h) -- used by tests/, bench.py and __graft_entry__.
+
+Thin by design: every method is one C-ABI call.  There is NO fallback: if libnbx.so is missing
+the import of the library fails loudly, and without a HIP device nbx_create() returns
+NBX_ERR_DEVICE which is raised as NbxError.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnbx.so")
+
+NBX_OK, NBX_ERR_ARG, NBX_ERR_DEVICE, NBX_ERR_STATE, NBX_ERR_ALLOC = 0, -1, -2, -3, -4
+KERNEL_AUTO, KERNEL_LDS, KERNEL_SGPR = 0, 1, 2
+
+# every symbol include/nbx.h declares (tests check the library exports each of them)
+SYMBOLS = (
+    "nbx_last_error", "nbx_abi_version", "nbx_create", "nbx_destroy", "nbx_upload", "nbx_step",
+    "nbx_step_trace", "nbx_step_local", "nbx_exchange_buffer", "nbx_commit", "nbx_kenergy_partial",
+    "nbx_accel", "nbx_sync", "nbx_download", "nbx_ic_pos", "nbx_ic_vel", "nbx_ic_mass", "nbx_profile",
+    "nbx_stats",
+)
+
+
+class NbxError(RuntimeError):
+    def __init__(self, code, where, text):
+        super().__init__("%s failed (%d): %s" % (where, code, text))
+        self.code = code
+
+
+class Opts(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_int32), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
+        ("i_begin", ctypes.c_int32), ("i_count", ctypes.c_int32), ("n_alloc", ctypes.c_int32),
+        ("bodies_per_lane", ctypes.c_int32), ("j_split", ctypes.c_int32), ("kernel_variant", ctypes.c_int32),
+        ("fused_epilogue", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5),
+    ]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_int32), ("n_alloc", ctypes.c_int32), ("i_begin", ctypes.c_int32), ("i_count", ctypes.c_int32),
+        ("precision", ctypes.c_int32), ("bodies_per_lane", ctypes.c_int32), ("j_split", ctypes.c_int32),
+        ("j_tile", ctypes.c_int32), ("kernel_variant", ctypes.c_int32), ("fused_epilogue", ctypes.c_int32),
+        ("force_grid_x", ctypes.c_int32), ("force_grid_y", ctypes.c_int32), ("force_block", ctypes.c_int32),
+        ("cu_count", ctypes.c_int32), ("clock_mhz", ctypes.c_int32), ("steps_done", ctypes.c_int64),
+        ("force_launches_timed", ctypes.c_int64), ("force_ms_total", ctypes.c_double),
+        ("pairs_per_launch", ctypes.c_double), ("device_name", ctypes.c_char * 64),
+    ]
+
+    def asdict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["device_name"] = self.device_name.decode(errors="replace")
+        return d
+
+
+_lib = None
+
+
+def load():
+    """Load libnbx.so (raises OSError with a build hint if it is not there)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("%s not found: build it with `make lib` (or __graft_entry__.build()); "
+                      "there is no fallback path" % LIB_PATH)
+    if "torch" not in sys.modules and not os.environ.get("NBX_NO_TORCH_PRELOAD"):
+        # The PyTorch-ROCm wheel bundles its own libamdhip64 / libhsa-runtime64.  Two copies of the
+        # ROCm runtime cannot both initialise in one process (the second one sees no GPU), so when
+        # torch is installed let it load first: libnbx.so then binds to the copy torch brought
+        # (same sonames).  Stand-alone consumers (nbody.x) use /opt/rocm's copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_double
+    L.nbx_last_error.restype = ctypes.c_char_p
+    L.nbx_abi_version.restype = i32
+    L.nbx_create.argtypes = [ctypes.POINTER(vp), i32, i32, ctypes.POINTER(Opts)]
+    L.nbx_destroy.argtypes = [vp]
+    L.nbx_destroy.restype = None
+    L.nbx_upload.argtypes = [vp] + [vp] * 7
+    L.nbx_step.argtypes = [vp, dbl, i32, ctypes.POINTER(dbl)]
+    L.nbx_step_trace.argtypes = [vp, dbl, i32, vp]
+    L.nbx_step_local.argtypes = [vp, dbl]
+    L.nbx_exchange_buffer.argtypes = [vp, ctypes.POINTER(vp)] + [ctypes.POINTER(ctypes.c_size_t)] * 3
+    L.nbx_commit.argtypes = [vp]
+    L.nbx_kenergy_partial.argtypes = [vp, ctypes.POINTER(dbl)]
+    L.nbx_accel.argtypes = [vp, vp, vp, vp]
+    L.nbx_sync.argtypes = [vp]
+    L.nbx_download.argtypes = [vp] + [vp] * 6
+    L.nbx_ic_pos.argtypes = [i32, i32, vp, vp, vp]
+    L.nbx_ic_vel.argtypes = [i32, i32, vp, vp, vp]
+    L.nbx_ic_mass.argtypes = [i32, i32, vp]
+    L.nbx_profile.argtypes = [vp, i32]
+    L.nbx_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    _lib = L
+    return L
+
+
+def _check(rc, where):
+    if rc != NBX_OK:
+        raise NbxError(rc, where, load().nbx_last_error().decode(errors="replace"))
+
+
+def _dtype(precision):
+    if precision == 32:
+        return np.float32
+    if precision == 64:
+        return np.float64
+    raise NbxError(NBX_ERR_ARG, "precision", "must be 32 or 64")
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+DT = float(np.float32(0.1))  # (float)0.1 widened: the reference's _tstep (ver7/GSimulation.cpp:30)
+
+FIELDS = ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass")
+
+
+def initial_conditions(n, precision=32):
+    """Seed-42 particles of ver7/GSimulation.cpp:45-94 as a dict of seven arrays."""
+    L = load()
+    dt = _dtype(precision)
+    s = {f: np.zeros(max(n, 0), dtype=dt) for f in FIELDS}
+    _check(L.nbx_ic_pos(n, precision, _ptr(s["pos_x"]), _ptr(s["pos_y"]), _ptr(s["pos_z"])), "nbx_ic_pos")
+    _check(L.nbx_ic_vel(n, precision, _ptr(s["vel_x"]), _ptr(s["vel_y"]), _ptr(s["vel_z"])), "nbx_ic_vel")
+    _check(L.nbx_ic_mass(n, precision, _ptr(s["mass"])), "nbx_ic_mass")
+    return s
+
+
+class Context:
+    """One nbx_ctx.  Keyword options are the nbx_opts fields."""
+
+    def __init__(self, n, precision=32, **opts):
+        self._L = load()
+        self._h = ctypes.c_void_p()
+        self.n = int(n)
+        self.precision = int(precision)
+        o = Opts()
+        o.struct_size = ctypes.sizeof(Opts)
+        o.device = -1
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError("unknown nbx_opts field %r" % k)
+            setattr(o, k, v)
+        _check(self._L.nbx_create(ctypes.byref(self._h), self.n, self.precision, ctypes.byref(o)), "nbx_create")
+        self.dtype = _dtype(self.precision)
+
+    def close(self):
+        if self._h:
+            self._L.nbx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _arr(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.shape != (self.n,):
+            raise NbxError(NBX_ERR_ARG, "array", "expected shape (%d,), got %r" % (self.n, a.shape))
+        return a
+
+    def upload(self, state):
+        arrs = [self._arr(state[f]) for f in FIELDS]
+        _check(self._L.nbx_upload(self._h, *[_ptr(a) for a in arrs]), "nbx_upload")
+
+    def step(self, nsteps, dt=DT, kenergy=True):
+        ke = ctypes.c_double(0.0)
+        _check(self._L.nbx_step(self._h, dt, nsteps, ctypes.byref(ke) if kenergy else None), "nbx_step")
+        return ke.value if kenergy else None
+
+    def step_trace(self, nsteps, dt=DT):
+        ke = np.zeros(max(nsteps, 1), dtype=np.float64)
+        _check(self._L.nbx_step_trace(self._h, dt, nsteps, _ptr(ke)), "nbx_step_trace")
+        return ke[:nsteps]
+
+    def step_local(self, dt=DT):
+        _check(self._L.nbx_step_local(self._h, dt), "nbx_step_local")
+
+    def exchange_buffer(self):
+        p = ctypes.c_void_p()
+        tot, off, own = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        _check(self._L.nbx_exchange_buffer(self._h, ctypes.byref(p), ctypes.byref(tot), ctypes.byref(off),
+                                           ctypes.byref(own)), "nbx_exchange_buffer")
+        return p.value, tot.value, off.value, own.value
+
+    def commit(self):
+        _check(self._L.nbx_commit(self._h), "nbx_commit")
+
+    def kenergy_partial(self):
+        s = ctypes.c_double(0.0)
+        _check(self._L.nbx_kenergy_partial(self._h, ctypes.byref(s)), "nbx_kenergy_partial")
+        return s.value
+
+    def accel(self):
+        a = [np.zeros(self.n, dtype=self.dtype) for _ in range(3)]
+        _check(self._L.nbx_accel(self._h, *[_ptr(x) for x in a]), "nbx_accel")
+        return a
+
+    def sync(self):
+        _check(self._L.nbx_sync(self._h), "nbx_sync")
+
+    def download(self):
+        out = {f: np.zeros(self.n, dtype=self.dtype) for f in FIELDS[:6]}
+        _check(self._L.nbx_download(self._h, *[_ptr(out[f]) for f in FIELDS[:6]]), "nbx_download")
+        return out
+
+    def profile(self, enable=True):
+        _check(self._L.nbx_profile(self._h, 1 if enable else 0), "nbx_profile")
+
+    def stats(self):
+        s = Stats()
+        _check(self._L.nbx_stats(self._h, ctypes.byref(s)), "nbx_stats")
+        return s.asdict()

@@ -1,0 +1,171 @@
+"""Block-partitioned stepping across ranks: one process per GPU, torch.distributed for the exchange.
+
+The reference's only distributed design is root-centric MPI: every step rank 0 broadcasts nine
+n-float arrays and gathers three acceleration slices back (ver5_all/GSimulation.cpp:170-214,
+cpu/Compute.cpp:47-58, 95-97); its OpenCL back end splits the i range across devices the same
+way (opencl/Compute.cpp:241-255, 273).  Here the same i-block partition is kept but each rank
+owns its bodies for good: it integrates them itself, velocities never travel, and the only
+exchange per time step is ONE in-place all-gather of the freshly integrated {x,y,z,G*m} blocks
+(RCCL over xGMI when the backend is "nccl").  Kinetic energy is a scalar all-reduce, done only
+when a caller asks for it.
+
+PyTorch is plumbing here: rendezvous, the collective, barriers.  The compute is libnbx.
+"""
+import ctypes
+
+import numpy as np
+
+BLOCK_ALIGN = 256  # = the kernels' j tile: keeps every rank's block a whole number of tiles
+
+
+def block_partition(n, world, rank, align=BLOCK_ALIGN):
+    """Balanced block partition with equal, tile-aligned blocks.
+
+    Returns (block, i_begin, i_count, n_alloc).  All ranks hold n_alloc = world*block records;
+    records >= n are zero-mass padding (their pair terms are exactly 0).  Unlike the reference's
+    slices (cpu/Compute.cpp:50-51, wrong unless n % size == 0) any n works; trailing ranks may
+    own fewer (or zero) real bodies.
+    """
+    if n <= 0 or world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad partition arguments n=%r world=%r rank=%r" % (n, world, rank))
+    block = -(-n // world)
+    block = -(-block // align) * align
+    i_begin = min(rank * block, n)
+    i_count = max(0, min(n, (rank + 1) * block) - i_begin)
+    return block, i_begin, i_count, world * block
+
+
+class _DeviceBuffer:
+    """Zero-copy view of a raw device pointer for torch.as_tensor (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {
+            "shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2, "strides": None,
+        }
+
+
+def _nbx():
+    """Import nbx.py by path (the package directory name contains '-')."""
+    import importlib.util
+    import os
+    import sys
+    if "nbx" in sys.modules:
+        return sys.modules["nbx"]
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("nbx", os.path.join(here, "nbx.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["nbx"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class NbxEngine:
+    """libnbx context of one rank (the product path): owns [i_begin, i_begin+i_count)."""
+
+    def __init__(self, n, precision, i_begin, i_count, n_alloc, **opts):
+        import torch
+        nbx = _nbx()
+        self.torch = torch
+        self.precision = precision
+        self.stream = torch.cuda.current_stream()
+        if i_count <= 0:
+            raise ValueError("a rank with no bodies cannot build a context (n too small for this world size)")
+        self.ctx = nbx.Context(n, precision, i_begin=i_begin, i_count=i_count, n_alloc=n_alloc,
+                               stream=ctypes.c_void_p(self.stream.cuda_stream), **opts)
+        self._views = {}
+
+    def upload(self, state):
+        self.ctx.upload(state)
+
+    def step_local(self, dt):
+        self.ctx.step_local(dt)
+
+    def exchange_tensor(self):
+        """uint8 tensor aliasing the whole NEXT position buffer (n_alloc records)."""
+        ptr, total, _, _ = self.ctx.exchange_buffer()
+        t = self._views.get(ptr)
+        if t is None:
+            t = self.torch.as_tensor(_DeviceBuffer(ptr, total), device="cuda")
+            self._views[ptr] = t
+        return t
+
+    def commit(self):
+        self.ctx.commit()
+
+    def kenergy_partial(self):
+        return self.ctx.kenergy_partial()
+
+    def download(self):
+        return self.ctx.download()
+
+    def sync(self):
+        self.ctx.sync()
+
+    def close(self):
+        self.ctx.close()
+
+
+class ShardedSimulation:
+    """The reference's time-step loop (ver7/GSimulation.cpp:138-200) over `world` ranks.
+
+    engine_factory(n, precision, i_begin, i_count, n_alloc) builds the rank's compute engine
+    (default: NbxEngine = libnbx on the rank's GPU).  `dist` is torch.distributed, already
+    initialised (nccl == RCCL on ROCm; gloo for CPU rehearsals), or None for a single rank.
+    """
+
+    def __init__(self, n, precision=32, dist=None, engine_factory=None, **opts):
+        self.n = int(n)
+        self.precision = precision
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.block, self.i_begin, self.i_count, self.n_alloc = block_partition(self.n, self.world, self.rank)
+        self.rec = 16 if precision == 32 else 32
+        factory = engine_factory or NbxEngine
+        self.engine = factory(self.n, precision, self.i_begin, self.i_count, self.n_alloc, **opts)
+        self.steps_done = 0
+        self.bytes_gathered = 0
+
+    def upload(self, state):
+        self.engine.upload(state)
+
+    def _all_gather_in_place(self, full):
+        """In-place all-gather: rank r contributes full[r*block : (r+1)*block] (in records)."""
+        import torch
+        nb = self.block * self.rec
+        own = full[self.rank * nb:(self.rank + 1) * nb]
+        if full.is_cuda and self.dist.get_backend() != "nccl":
+            # rehearsal only (several ranks sharing one GPU under gloo): stage through the host
+            host = torch.empty(full.numel(), dtype=full.dtype)
+            self.dist.all_gather_into_tensor(host, own.cpu())
+            full.copy_(host)
+        else:
+            self.dist.all_gather_into_tensor(full, own)
+        self.bytes_gathered += nb * (self.world - 1)
+
+    def step(self, nsteps=1, dt=None):
+        dt = _nbx().DT if dt is None else dt
+        for _ in range(nsteps):
+            self.engine.step_local(dt)
+            if self.dist:
+                self._all_gather_in_place(self.engine.exchange_tensor())
+            self.engine.commit()
+            self.steps_done += 1
+
+    def kenergy(self):
+        """_kenergy of ver7/GSimulation.cpp:200 after the last step (synchronises)."""
+        import torch
+        part = float(self.engine.kenergy_partial())
+        if self.dist:
+            t = torch.tensor([part], dtype=torch.float64)
+            if self.dist.get_backend() == "nccl":
+                t = t.cuda()
+            self.dist.all_reduce(t)
+            part = float(t.item())
+        return 0.5 * part
+
+    def sync(self):
+        self.engine.sync()
+
+    def close(self):
+        self.engine.close()

@@ -163,7 +163,7 @@ int main(int argc, char **argv) {
   std::cout.rdbuf(saved);
 
   // rows: " s  s*dt  kenergy  time  gflops" -- keep column 3
-  std::vector<std::string> ke;
+  std::vector<std::string> ke, secs;
   std::istringstream in(sink.str());
   std::string line;
   while (std::getline(in, line)) {
@@ -174,9 +174,13 @@ int main(int argc, char **argv) {
     long s = strtol(a.c_str(), &endp, 10);
     if (*endp != 0 || s < 1) continue;
     ke.push_back(c);
+    secs.push_back(d);  // the reference's own (ts1 - ts0) for this step: both loops, no printing
   }
   fprintf(f, "  \"kenergy\": [");
   for (size_t i = 0; i < ke.size(); ++i) fprintf(f, "%s%s", i ? ", " : "", ke[i].c_str());
+  fprintf(f, "],\n");
+  fprintf(f, "  \"step_seconds\": [");
+  for (size_t i = 0; i < secs.size(); ++i) fprintf(f, "%s%s", i ? ", " : "", secs[i].c_str());
   fprintf(f, "],\n");
   fprintf(f, "  \"kenergy_last_member\": %.17g,\n", (double)sim._kenergy);
   dump_state(f, "final", sim.particles, n, nsample, true);

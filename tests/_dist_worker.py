@@ -1,0 +1,99 @@
+"""Worker for test_sharded_gloo.py: one rank of a world_size-N gloo job on the CPU.
+
+Exercises the product's multi-rank HOST logic (nbody-demo-2023_amd/sharded.py: block partition,
+in-place all-gather of the position blocks, scalar all-reduce of the energy partials) with the
+compute engine replaced by the oracle -- test infrastructure standing in for the GPU, so the
+collective pattern can be rehearsed where no GPU exists.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nbody-demo-2023_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import oracle as O  # noqa: E402
+import sharded  # noqa: E402
+
+G = np.float32(6.67259e-11)
+
+
+class OracleEngine:
+    """Same interface as sharded.NbxEngine, arithmetic by oracle/nbody_oracle.c."""
+
+    def __init__(self, n, precision, i_begin, i_count, n_alloc, **opts):
+        assert precision == 32
+        self.n, self.i0, self.i1, self.n_alloc = n, i_begin, i_begin + i_count, n_alloc
+        self.rec = [np.zeros((n_alloc, 4), dtype=np.float32) for _ in range(2)]
+        self.cur = 0
+        self.s = None
+        self.energy = 0.0
+
+    def upload(self, state):
+        s = O.State(self.n)
+        for f in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass"):
+            getattr(s, f)[:] = state[f]
+        self.s = s
+        for r in self.rec:
+            r[: self.n, 0], r[: self.n, 1], r[: self.n, 2], r[: self.n, 3] = s.pos_x, s.pos_y, s.pos_z, G * s.mass
+
+    def step_local(self, dt):
+        s = self.s
+        cur = self.rec[self.cur]
+        s.pos_x[:], s.pos_y[:], s.pos_z[:] = cur[: self.n, 0], cur[: self.n, 1], cur[: self.n, 2]
+        O.accel(s, self.i0, self.i1)
+        self.energy = float(O.integrate(s, dt, self.i0, self.i1))
+        nxt = self.rec[self.cur ^ 1]
+        sl = slice(self.i0, self.i1)
+        nxt[sl, 0], nxt[sl, 1], nxt[sl, 2] = s.pos_x[sl], s.pos_y[sl], s.pos_z[sl]
+
+    def exchange_tensor(self):
+        return torch.from_numpy(self.rec[self.cur ^ 1].reshape(-1).view(np.uint8))
+
+    def commit(self):
+        self.cur ^= 1
+
+    def kenergy_partial(self):
+        return self.energy
+
+    def positions(self):
+        r = self.rec[self.cur]
+        return r[: self.n, :3].copy()
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def main():
+    n, steps, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    sim = sharded.ShardedSimulation(n, 32, dist=dist, engine_factory=OracleEngine)
+    ic = O.init_state(n)
+    sim.upload({f: getattr(ic, f) for f in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass")})
+    ke = []
+    for _ in range(steps):
+        sim.step(1, dt=float(O.DT_F32))
+        ke.append(sim.kenergy())
+    pos = sim.engine.positions()
+    res = {"rank": rank, "world": world, "ke": ke, "i_begin": sim.i_begin, "i_count": sim.i_count,
+           "block": sim.block, "n_alloc": sim.n_alloc, "bytes_gathered": sim.bytes_gathered,
+           "pos_crc": int(np.frombuffer(pos.tobytes(), dtype=np.uint32).sum() & 0xFFFFFFFF)}
+    with open("%s.%d" % (out, rank), "w") as f:
+        json.dump(res, f)
+    np.save("%s.%d.npy" % (out, rank), pos)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

