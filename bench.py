@@ -158,7 +158,10 @@ def main():
     import sharded
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # NBX_BENCH_FORCE_DIST=1 rehearses the RCCL path with a 1-rank group (the only way to run it on a 1-GPU box)
+    force_dist = bool(os.environ.get("NBX_BENCH_FORCE_DIST")) and "RANK" in os.environ
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     opts = dict(bodies_per_lane=a.bodies_per_lane, j_split=a.j_split,
@@ -167,13 +170,13 @@ def main():
     parity = parity_probe(nbx, n, a.precision) if (rank == 0 and world == 1) else None
 
     ic = nbx.initial_conditions(n, a.precision)  # synthetic: the reference's seed-42 generator
-    sim = sharded.ShardedSimulation(n, a.precision, dist=dist if world > 1 else None, **opts)
+    sim = sharded.ShardedSimulation(n, a.precision, dist=dist if use_dist else None, force_collective=force_dist, **opts)
     sim.upload(ic)
 
     def fence():
         sim.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -185,7 +188,7 @@ def main():
     fence()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -235,7 +238,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     sim.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

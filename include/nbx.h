@@ -54,7 +54,8 @@ typedef struct nbx_ctx nbx_ctx;
 typedef struct nbx_opts {
   int32_t struct_size;     /* = sizeof(nbx_opts); 0 is accepted as "this version" */
   int32_t device;          /* HIP device ordinal; -1 = keep the current device */
-  void*   stream;          /* hipStream_t to enqueue on; NULL = the context creates its own */
+  void*   stream;          /* hipStream_t to enqueue on when external_stream != 0 (NULL then means the
+                              default stream); ignored otherwise: the context creates its own stream */
   int32_t i_begin;         /* first body this context owns (integrates) */
   int32_t i_count;         /* bodies owned; 0 = all n (single-GPU) */
   int32_t n_alloc;         /* length of the device {x,y,z,G*m} array, >= n; 0 = n rounded up to the
@@ -65,7 +66,8 @@ typedef struct nbx_opts {
   int32_t fused_epilogue;  /* 0 = auto (fused when j_split == 1), 1 = on where possible, 2 = off
                               (always the separate integrate kernel) */
   int32_t use_graph;       /* 0 = auto, 1 = replay multi-step windows from a hipGraph, 2 = plain launches */
-  int32_t reserved[5];
+  int32_t external_stream; /* 0 = own non-blocking stream; 1 = enqueue everything on `stream` (caller-owned) */
+  int32_t reserved[4];
 } nbx_opts;
 
 typedef struct nbx_stats_t {

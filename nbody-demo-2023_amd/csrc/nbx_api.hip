@@ -359,8 +359,8 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
 
   CREATE_TRY(hipSetDevice(dev));
   CREATE_TRY(hipGetDeviceProperties(&c->prop, dev));
-  if (o.stream) {
-    c->stream = (hipStream_t)o.stream;
+  if (o.external_stream) {
+    c->stream = (hipStream_t)o.stream;  // may be NULL: the default stream
   } else {
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->own_stream = true;

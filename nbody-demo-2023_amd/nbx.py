@@ -36,7 +36,8 @@ class Opts(ctypes.Structure):
         ("struct_size", ctypes.c_int32), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p),
         ("i_begin", ctypes.c_int32), ("i_count", ctypes.c_int32), ("n_alloc", ctypes.c_int32),
         ("bodies_per_lane", ctypes.c_int32), ("j_split", ctypes.c_int32), ("kernel_variant", ctypes.c_int32),
-        ("fused_epilogue", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5),
+        ("fused_epilogue", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("external_stream", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 4),
     ]
 
 

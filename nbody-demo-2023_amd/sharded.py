@@ -67,11 +67,13 @@ class NbxEngine:
         nbx = _nbx()
         self.torch = torch
         self.precision = precision
+        # the context enqueues on torch's CURRENT stream (handle 0 = the default stream), so the
+        # collectives torch issues on that stream are ordered with the kernels
         self.stream = torch.cuda.current_stream()
         if i_count <= 0:
             raise ValueError("a rank with no bodies cannot build a context (n too small for this world size)")
         self.ctx = nbx.Context(n, precision, i_begin=i_begin, i_count=i_count, n_alloc=n_alloc,
-                               stream=ctypes.c_void_p(self.stream.cuda_stream), **opts)
+                               stream=ctypes.c_void_p(self.stream.cuda_stream), external_stream=1, **opts)
         self._views = {}
 
     def upload(self, state):
@@ -113,10 +115,12 @@ class ShardedSimulation:
     initialised (nccl == RCCL on ROCm; gloo for CPU rehearsals), or None for a single rank.
     """
 
-    def __init__(self, n, precision=32, dist=None, engine_factory=None, **opts):
+    def __init__(self, n, precision=32, dist=None, engine_factory=None, force_collective=False, **opts):
         self.n = int(n)
         self.precision = precision
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        # a 1-rank group skips the collectives unless force_collective (used to rehearse the RCCL path on one GPU)
+        use = dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)
+        self.dist = dist if use else None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.rank = self.dist.get_rank() if self.dist else 0
         self.block, self.i_begin, self.i_count, self.n_alloc = block_partition(self.n, self.world, self.rank)

@@ -334,3 +334,42 @@ def test_fullsize_padding_bodies_are_inert(nbx):
     # same split count but different split boundaries: agree to rounding, not bitwise
     scale = np.abs(a1[0]).max()
     assert np.abs(a1[0] - a2[0]).max() / scale < 1e-5
+
+
+# ---- the product engine under torch.distributed (rehearsals possible on a 1-GPU box) ------------
+def _run_ranks(tmp_path, n, steps, world, backend):
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    out = str(tmp_path / "res")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), str(n), str(steps), out, backend]
+    p = subprocess.run(cmd, env=env, timeout=600, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return [json.load(open("%s.%d" % (out, r))) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (3, "gloo"), (1, "nccl")])
+def test_product_engine_under_torch_distributed(nbx, tmp_path, world, backend):
+    """NbxEngine + ShardedSimulation end to end: device buffer aliased as a torch tensor, context on torch's
+    stream, in-place all-gather, energy all-reduce.  gloo: `world` ranks share cuda:0 (exchange staged through the
+    host); nccl: a 1-rank RCCL group with the collectives forced on.  Must be bit-equal to a single context."""
+    import sharded
+    n, steps = 3001, 8
+    res = _run_ranks(tmp_path, n, steps, world, backend)
+    n_alloc = sharded.block_partition(n, world, 0)[3]
+    with nbx.Context(n, j_split=4, bodies_per_lane=2, n_alloc=n_alloc) as c:
+        c.upload(nbx.initial_conditions(n))
+        ke = c.step_trace(steps)
+        px = c.download()["pos_x"]
+    for r in res:
+        assert r["world"] == world and r["n_alloc"] == n_alloc
+        assert r["pos_x"] == px.tolist()[:64] + px.tolist()[-64:]
+        assert rel_err(r["ke"], ke).max() < 1e-12
+    assert sum(r["i_count"] for r in res) == n
