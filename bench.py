@@ -143,7 +143,8 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
         a.gpus = world
     n = a.n or (262144 if a.gpus == 1 else 1048576)
-    workload = ("BASELINE.json configs[2]: 1xMI355X nPart=262144 fp32" if (n == 262144 and a.gpus == 1) else
+    workload = ("BASELINE.json configs[4]: 1xMI355X nPart=262144 fp64 variant" if (n == 262144 and a.gpus == 1 and a.precision == 64) else
+                "BASELINE.json configs[2]: 1xMI355X nPart=262144 fp32" if (n == 262144 and a.gpus == 1) else
                 "BASELINE.json configs[3]: nPart=1048576 block-partitioned, all-gather(pos) per step" if n == 1048576 else
                 "nPart=%d" % n)
 
@@ -206,7 +207,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("n") == n and tj.get("gpus", 1) == a.gpus:
+                if tj.get("n") == n and tj.get("gpus", 1) == a.gpus and tj.get("precision", 32) == a.precision:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -226,8 +227,8 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": st["pairs_per_launch"],
                          "launch_ms_avg": launch_ms, "launches_timed": st["force_launches_timed"],
-                         "note": "fp32 vector FMA roofline (north_star: FMA/rsqrt-bound, no MFMA); 157.3 TFLOP/s is "
-                                 "also the dense f32 MFMA peak.  HBM is not the bound: see DESIGN.md"},
+                         "note": "fp%d vector FMA roofline (north_star: FMA/rsqrt-bound, no MFMA); for fp32 the 157.3 "
+                                 "TFLOP/s is also the dense f32 MFMA peak.  HBM is not the bound: see DESIGN.md" % a.precision},
             "device": st["device_name"], "cu_count": st["cu_count"],
         }
         if parity:

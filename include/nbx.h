@@ -40,8 +40,9 @@ enum {
 /* kernel_variant values */
 enum {
   NBX_KERNEL_AUTO = 0,
-  NBX_KERNEL_LDS = 1,  /* j-tile staged in LDS, broadcast ds_read_b128 (the north-star design) */
-  NBX_KERNEL_SGPR = 2  /* j-bodies fetched by wave-uniform scalar loads into SGPRs */
+  NBX_KERNEL_LDS = 1,  /* j-tile (256 records) staged in LDS, broadcast ds_read_b128 (the north-star design) */
+  NBX_KERNEL_SGPR = 2  /* j-bodies fetched by wave-uniform scalar loads into SGPRs (AUTO picks this one:
+                          measured 4-6 % faster on MI355X, profiles/r01_kbench_*) */
 };
 
 typedef struct nbx_ctx nbx_ctx;

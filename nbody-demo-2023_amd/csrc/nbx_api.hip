@@ -112,25 +112,32 @@ ForceLauncher<T> pick_force(const nbx_ctx* c, bool fused) {
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
-// Choose register blocking B and j-split S so the launch has enough waves to fill 256 CUs
-// (measured with tools/kbench on MI355X; see DESIGN.md "launch shape").
+// Launch shape.  Measured with tools/kbench on MI355X (profiles/r01_kbench_*): the force kernel is
+// VALU-issue bound and wants all 8 wave slots of every SIMD filled, i.e. >= 8192 workgroups of 256
+// threads (32 per CU); B = 4 i-bodies per lane (two packed register pairs) with the j records in
+// SGPRs was the fastest shape from n = 16k to 1M (58-60 % of the fp32 roofline vs 52 % for
+// B = 8 / LDS tile / 1024 workgroups).  S j-range splits provide the workgroups the i range cannot.
 void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   const int cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
-  const int target_wgs = cus * 4;  // 4 workgroups (16 waves) per CU
+  const int target_wgs = cus * 32;
   const int max_split = std::max(1, c->n_alloc / kTile);
   const int maxB = c->precision == 32 ? 8 : 4;
   int B = o.bodies_per_lane;
   if (B != 1 && B != 2 && B != 4 && B != 8) B = 0;
   if (B > maxB) B = maxB;
   if (B == 0) {
-    B = maxB;
-    // shrink B while even the deepest useful split cannot reach the target
-    while (B > 2 && (long long)ceil_div(c->i_count, kBlock * B) * std::min(max_split, 64) < target_wgs) B /= 2;
+    B = 4;
+    // short i ranges: keep at least ~64 i-blocks so the split count stays moderate
+    while (B > 2 && ceil_div(c->i_count, kBlock * B) < 16) B /= 2;
   }
   int S = o.j_split;
   if (S <= 0) {
     const int bi = ceil_div(c->i_count, kBlock * B);
     S = ceil_div(target_wgs, bi);
+    // the S partial-acceleration slabs are written and re-read every step: keep them small
+    // next to the pair work (<= 64 splits, <= 256 MiB)
+    S = std::min(S, 64);
+    while (S > 1 && (size_t)S * c->own_pad * c->rec > ((size_t)256 << 20)) S /= 2;
   }
   S = std::max(1, std::min(S, max_split));
   int jps = round_up(ceil_div(c->n_alloc, S), kTile);
@@ -139,7 +146,7 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   c->S = S;
   c->jps = jps;
   c->math = (c->precision == 32 && B >= 2) ? MATH_PACKED : MATH_SCALAR;
-  c->variant = o.kernel_variant == NBX_KERNEL_SGPR ? NBX_KERNEL_SGPR : NBX_KERNEL_LDS;
+  c->variant = o.kernel_variant == NBX_KERNEL_LDS ? NBX_KERNEL_LDS : NBX_KERNEL_SGPR;
   // fused_epilogue: 0 auto, 1 on, 2 off; only possible without a j-split
   c->fused = (S == 1 && o.fused_epilogue != 2) ? 1 : 0;
   c->grid = dim3(ceil_div(c->i_count, kBlock * B), S);
@@ -236,7 +243,7 @@ int upload_t(nbx_ctx* c, const T* px, const T* py, const T* pz, const T* vx, con
   std::vector<T4> hp((size_t)c->n_alloc);
   const T G = grav_const<T>();
   for (int i = 0; i < c->n; ++i) {
-    T4 r; r.x = px[i]; r.y = py[i]; r.z = pz[i]; r.w = G * m[i];
+    T4 r; r.x = px[i]; r.y = py[i]; r.z = pz[i]; r.w = (G * m[i]) * gm_prescale<T>();
     hp[i] = r;
   }
   for (int i = c->n; i < c->n_alloc; ++i) { T4 z; z.x = z.y = z.z = z.w = (T)0; hp[i] = z; }
@@ -393,7 +400,7 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
 void nbx_destroy(nbx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream);  // NULL = the default stream when the caller lent us that one
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   if (c->posm[0]) (void)hipFree(c->posm[0]);
   if (c->posm[1]) (void)hipFree(c->posm[1]);

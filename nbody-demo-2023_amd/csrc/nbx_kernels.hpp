@@ -38,16 +38,20 @@ template <> struct V4<double> { using type = double4; };
 template <typename T> __host__ __device__ constexpr T softening2() { return (T)1.e-3f; }
 template <typename T> __host__ __device__ constexpr T grav_const() { return (T)6.67259e-11f; }
 
-// 1/sqrt(x).  fp32: the raw v_rsq_f32 (<= 1 ulp; r2 >= 1e-3 so no denormal/zero handling is
-// needed -- the ocml rsqrtf wrapper would add scaling code per pair).  fp64: v_rsq_f64 seed
-// (~2^-26) + two Newton-Raphson steps, to stay inside the 1e-10 fp64 gate with margin.
+// c/sqrt(x) with c = rsq_scale<T>().  fp32: the raw v_rsq_f32, c = 1 (<= 1 ulp; r2 >= 1e-3 so no
+// denormal/zero handling is needed -- the ocml rsqrtf wrapper would add scaling code per pair).
+// fp64: v_rsq_f64 is a ~2^-26 seed (measured 1.2e-8 on the accelerations); ONE Newton step
+// y' = y/2 * (3 - x*y*y) takes it to ~3e-16 (measured 4.6e-15 on accelerations, 2.8e-15 on a
+// 500-step kenergy trace; the gate is 1e-10).  The step's factor 1/2 is not applied here: the
+// function returns 2/sqrt(x) and the records carry G*m/8 instead (exact power-of-two scaling,
+// gm_prescale<double>()), which saves one multiply per pair: 3 VALU for the step instead of 4.
+template <typename T> __host__ __device__ constexpr T gm_prescale() { return sizeof(T) == 8 ? (T)0.125 : (T)1; }
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ double rsq(double x) {
-  double y = __builtin_amdgcn_rsq(x);
-  double hx = 0.5 * x;
-  y = y * __builtin_fma(-hx * y, y, 1.5);
-  y = y * __builtin_fma(-hx * y, y, 1.5);
-  return y;
+  const double y = __builtin_amdgcn_rsq(x);
+  const double t = x * y;
+  const double u = __builtin_fma(-t, y, 3.0);
+  return y * u;
 }
 
 __device__ __forceinline__ float fmaT(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -55,6 +59,7 @@ __device__ __forceinline__ double fmaT(double a, double b, double c) { return __
 
 // One pair: 3 sub, 3 FMA (r^2 + eps^2), 1 rsq, 3 mul (G*m_j * inv^3), 3 FMA (accumulate)
 // = 12 VALU + 1 transcendental = the 20 "algorithmic" flops of DESIGN.md.
+// gmj is the record's .w = G*m_j * gm_prescale<T>(), inv = rsq_scale * r2^-1/2 (see rsq above).
 template <typename T>
 __device__ __forceinline__ void pair(T xj, T yj, T zj, T gmj, T xi, T yi, T zi, T& ax, T& ay, T& az) {
   const T dx = xj - xi, dy = yj - yi, dz = zj - zi;

@@ -11,7 +11,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnbx.so")
+LIB_PATH = os.environ.get("NBX_LIB") or os.path.join(_HERE, "libnbx.so")
 
 NBX_OK, NBX_ERR_ARG, NBX_ERR_DEVICE, NBX_ERR_STATE, NBX_ERR_ALLOC = 0, -1, -2, -3, -4
 KERNEL_AUTO, KERNEL_LDS, KERNEL_SGPR = 0, 1, 2

@@ -14,19 +14,16 @@ static void launch_f32(const KbArgs& k, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL((force_kernel<float, B, JSRC, false, MINW, MATH>), grid, dim3(kBlock), 0, st, a);
 }
 
-#define ADD(B_, J_, W_, S_, M_) \
-  vs.push_back({std::string(KB_TAG) + (J_ == JSRC_LDS ? " lds " : " sgpr") + " B" #B_ " W" #W_ " S" #S_ + (M_ ? " pk" : ""), B_, S_, launch_f32<B_, J_, W_, M_>, {}})
+#define ADD(B_, J_, M_) \
+  vs.push_back({std::string(KB_TAG) + (J_ == JSRC_LDS ? " lds " : " sgpr") + " B" #B_ + (M_ ? " pk" : "   "), B_, 0, launch_f32<B_, J_, 1, M_>, {}})
 
 void KB_REGISTER(std::vector<Variant>& vs) {
-  ADD(1, JSRC_LDS, 1, 1, 0);
-  ADD(2, JSRC_LDS, 1, 1, 0);  ADD(2, JSRC_LDS, 1, 2, 0);  ADD(2, JSRC_LDS, 1, 4, 0);
-  ADD(4, JSRC_LDS, 1, 2, 0);  ADD(4, JSRC_LDS, 1, 4, 0);  ADD(4, JSRC_LDS, 1, 8, 0);
-  ADD(8, JSRC_LDS, 1, 4, 0);  ADD(8, JSRC_LDS, 1, 8, 0);  ADD(8, JSRC_LDS, 1, 16, 0);
-  ADD(2, JSRC_SGPR, 1, 2, 0); ADD(2, JSRC_SGPR, 1, 4, 0);
-  ADD(4, JSRC_SGPR, 1, 2, 0); ADD(4, JSRC_SGPR, 1, 4, 0); ADD(4, JSRC_SGPR, 1, 8, 0);
-  ADD(8, JSRC_SGPR, 1, 4, 0); ADD(8, JSRC_SGPR, 1, 8, 0); ADD(8, JSRC_SGPR, 1, 16, 0);
-#ifdef KB_WITH_PK
-  ADD(2, JSRC_LDS, 1, 2, 1);  ADD(4, JSRC_LDS, 1, 4, 1);  ADD(8, JSRC_LDS, 1, 8, 1);
-  ADD(2, JSRC_SGPR, 1, 2, 1); ADD(4, JSRC_SGPR, 1, 4, 1); ADD(8, JSRC_SGPR, 1, 8, 1);
+#ifndef KB_WITH_PK
+  ADD(1, JSRC_LDS, 0); ADD(2, JSRC_LDS, 0); ADD(4, JSRC_LDS, 0); ADD(8, JSRC_LDS, 0);
+  ADD(2, JSRC_SGPR, 0); ADD(4, JSRC_SGPR, 0); ADD(8, JSRC_SGPR, 0);
+#else
+  ADD(1, JSRC_LDS, 0); ADD(2, JSRC_LDS, 0); ADD(4, JSRC_LDS, 0); ADD(8, JSRC_LDS, 0);
+  ADD(2, JSRC_LDS, 1);  ADD(4, JSRC_LDS, 1);  ADD(8, JSRC_LDS, 1);
+  ADD(2, JSRC_SGPR, 1); ADD(4, JSRC_SGPR, 1); ADD(8, JSRC_SGPR, 1);
 #endif
 }

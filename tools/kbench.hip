@@ -1,6 +1,6 @@
 // kbench.hip -- development harness (not shipped in libnbx.so): A/B of force_kernel variants on
 // one GPU, interleaved rounds in ONE process (guide rule 24), random data, HIP-event timing.
-//   usage: kbench.x [n=262144] [rounds=5]
+//   usage: kbench.x [n=262144] [rounds=5] [S1,S2,...]   (every compiled variant x every j-split S)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
   std::uniform_real_distribution<float> U(0.f, 1.f);
   for (auto& p : h) { p.x = U(g); p.y = U(g); p.z = U(g); p.w = 6.67259e-11f * n * U(g); }
   float4 *posm, *accp;
-  const int maxS = 16;
+  const int maxS = 128;
   CK(hipMalloc(&posm, sizeof(float4) * n));
   CK(hipMalloc(&accp, sizeof(float4) * (size_t)n * maxS));
   CK(hipMemcpy(posm, h.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
@@ -48,9 +48,28 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
 
-  std::vector<Variant> vs;
-  reg_noslp(vs);
-  reg_slp(vs);
+  std::vector<int> splits;
+  {
+    std::string sl = argc > 3 ? argv[3] : "4,8";
+    size_t p0 = 0;
+    while (p0 < sl.size()) {
+      size_t p1 = sl.find(',', p0);
+      if (p1 == std::string::npos) p1 = sl.size();
+      splits.push_back(atoi(sl.substr(p0, p1 - p0).c_str()));
+      p0 = p1 + 1;
+    }
+  }
+  std::vector<Variant> base, vs;
+  reg_noslp(base);
+  reg_slp(base);
+  for (auto& b : base)
+    for (int S : splits) {
+      if (S > n / kTile) continue;
+      Variant v = b;
+      v.S = S;
+      v.name += " S" + std::to_string(S);
+      vs.push_back(v);
+    }
 
   // reference result for a cross-check: variant 0
   std::vector<float4> ref(n), got(n);
