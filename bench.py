@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--cpu-baseline", default="auto", choices=("auto", "reference", "port", "none"))
     ap.add_argument("--bodies-per-lane", type=int, default=0)
     ap.add_argument("--j-split", type=int, default=0)
-    ap.add_argument("--kernel", default="auto", choices=("auto", "lds", "sgpr"))
+    ap.add_argument("--kernel", default="auto", choices=("auto", "lds", "sgpr", "sgprw"))
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,7 +166,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     opts = dict(bodies_per_lane=a.bodies_per_lane, j_split=a.j_split,
-                kernel_variant={"auto": 0, "lds": 1, "sgpr": 2}[a.kernel])
+                kernel_variant={"auto": 0, "lds": 1, "sgpr": 2, "sgprw": 3}[a.kernel])
 
     parity = parity_probe(nbx, n, a.precision) if (rank == 0 and world == 1) else None
 
@@ -219,7 +219,7 @@ def main():
             "config": {"workload": workload, "n_bodies": n, "bodies_per_gpu": st["i_count"],
                        "parallelism": "i-block x%d" % a.gpus, "j_tile": st["j_tile"],
                        "bodies_per_lane": st["bodies_per_lane"], "j_split": st["j_split"],
-                       "kernel": {1: "lds", 2: "sgpr"}.get(st["kernel_variant"], "?"),
+                       "kernel": {1: "lds", 2: "sgpr", 3: "sgprw"}.get(st["kernel_variant"], "?"),
                        "grid": [st["force_grid_x"], st["force_grid_y"]], "block": st["force_block"]},
             "gflops_reference_convention": 1e-9 * (29.0 * pairs_per_step + 19.0 * n) * a.steps / elapsed,
             "kenergy_after_run": ke,

@@ -39,10 +39,10 @@ enum {
 
 /* kernel_variant values */
 enum {
-  NBX_KERNEL_AUTO = 0,
-  NBX_KERNEL_LDS = 1,  /* j-tile (256 records) staged in LDS, broadcast ds_read_b128 (the north-star design) */
-  NBX_KERNEL_SGPR = 2  /* j-bodies fetched by wave-uniform scalar loads into SGPRs (AUTO picks this one:
-                          measured 4-6 % faster on MI355X, profiles/r01_kbench_*) */
+  NBX_KERNEL_AUTO = 0,  /* = NBX_KERNEL_SGPRW, the fastest measured on MI355X (profiles/r01_kbench_*) */
+  NBX_KERNEL_LDS = 1,   /* j-tile (256 records) staged in LDS, broadcast ds_read_b128 (the north-star design) */
+  NBX_KERNEL_SGPR = 2,  /* j records fetched by pipelined wave-uniform scalar loads into SGPRs */
+  NBX_KERNEL_SGPRW = 3  /* as SGPR, and the 4 waves of a workgroup share 64*B bodies and split the j range */
 };
 
 typedef struct nbx_ctx nbx_ctx;
@@ -81,6 +81,9 @@ typedef struct nbx_stats_t {
   double  force_ms_total;      /* sum of HIP-event durations of those launches (profiling on) */
   double  pairs_per_launch;    /* i_count * n */
   char    device_name[64];
+  int64_t graph_replays;       /* hipGraph launches issued by nbx_step (each covers up to 20 steps) */
+  int32_t use_graph;           /* 1 if nbx_step replays windows from a hipGraph */
+  int32_t reserved;
 } nbx_stats_t;
 
 /* Text of the last error on the calling thread ("" if none). Never NULL. */

@@ -64,6 +64,11 @@ struct nbx_ctx {
   long long force_timed = 0;
   hipDeviceProp_t prop{};
   dim3 grid;
+  // hipGraph replay of multi-step windows (launch-bound small n)
+  bool use_graph = false;
+  struct GraphUnit { int steps; int parity; double dt; hipGraphExec_t exec; };
+  std::vector<GraphUnit> graphs;
+  long long graph_replays = 0;
 };
 
 namespace {
@@ -71,24 +76,24 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // kernel dispatch
 // ------------------------------------------------------------------------------------------
-template <typename T, int B, int JSRC, bool FUSED, int MATH>
+template <typename T, int B, int JSRC, bool FUSED, int MATH, bool WS>
 void launch_force_t(const ForceArgs<T>& a, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((force_kernel<T, B, JSRC, FUSED, 1, MATH>), grid, dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((force_kernel<T, B, JSRC, FUSED, 1, MATH, WS>), grid, dim3(kBlock), 0, st, a);
 }
 
 template <typename T>
 using ForceLauncher = void (*)(const ForceArgs<T>&, dim3, hipStream_t);
 
-template <typename T, int JSRC, bool FUSED, int MATH>
+template <typename T, int JSRC, bool FUSED, int MATH, bool WS>
 ForceLauncher<T> pick_b(int B) {
   switch (B) {
     case 1:
-      if constexpr (MATH == MATH_SCALAR) return launch_force_t<T, 1, JSRC, FUSED, MATH>;
+      if constexpr (MATH == MATH_SCALAR) return launch_force_t<T, 1, JSRC, FUSED, MATH, WS>;
       return nullptr;
-    case 2: return launch_force_t<T, 2, JSRC, FUSED, MATH>;
-    case 4: return launch_force_t<T, 4, JSRC, FUSED, MATH>;
+    case 2: return launch_force_t<T, 2, JSRC, FUSED, MATH, WS>;
+    case 4: return launch_force_t<T, 4, JSRC, FUSED, MATH, WS>;
     case 8:
-      if constexpr (sizeof(T) == 4) return launch_force_t<T, 8, JSRC, FUSED, MATH>;
+      if constexpr (sizeof(T) == 4 && !WS) return launch_force_t<T, 8, JSRC, FUSED, MATH, WS>;
       return nullptr;
   }
   return nullptr;
@@ -96,9 +101,10 @@ ForceLauncher<T> pick_b(int B) {
 
 template <typename T, int MATH>
 ForceLauncher<T> pick(int B, int variant, bool fused) {
+  if (variant == NBX_KERNEL_SGPRW) return fused ? nullptr : pick_b<T, JSRC_SGPR, false, MATH, true>(B);
   if (variant == NBX_KERNEL_SGPR)
-    return fused ? pick_b<T, JSRC_SGPR, true, MATH>(B) : pick_b<T, JSRC_SGPR, false, MATH>(B);
-  return fused ? pick_b<T, JSRC_LDS, true, MATH>(B) : pick_b<T, JSRC_LDS, false, MATH>(B);
+    return fused ? pick_b<T, JSRC_SGPR, true, MATH, false>(B) : pick_b<T, JSRC_SGPR, false, MATH, false>(B);
+  return fused ? pick_b<T, JSRC_LDS, true, MATH, false>(B) : pick_b<T, JSRC_LDS, false, MATH, false>(B);
 }
 
 template <typename T>
@@ -114,42 +120,43 @@ int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 // Launch shape.  Measured with tools/kbench on MI355X (profiles/r01_kbench_*): the force kernel is
 // VALU-issue bound and wants all 8 wave slots of every SIMD filled, i.e. >= 8192 workgroups of 256
-// threads (32 per CU); B = 4 i-bodies per lane (two packed register pairs) with the j records in
-// SGPRs was the fastest shape from n = 16k to 1M (58-60 % of the fp32 roofline vs 52 % for
-// B = 8 / LDS tile / 1024 workgroups).  S j-range splits provide the workgroups the i range cannot.
+// threads (32 per CU).  Fastest shape from n = 2k to 1M: j records in SGPRs, the four waves of a
+// workgroup sharing 64*B bodies and splitting the j range (NBX_KERNEL_SGPRW), B = 4 bodies per lane
+// (two packed register pairs; B = 2 for short i ranges), plus S j-range splits across workgroups:
+// 58-60 % of the fp32 roofline at n >= 64k, 52 % at 16k, vs 52 % / 36 % for B = 8 / LDS tile.
 void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   const int cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
   const int target_wgs = cus * 32;
-  const int max_split = std::max(1, c->n_alloc / kTile);
-  const int maxB = c->precision == 32 ? 8 : 4;
+  int variant = o.kernel_variant;
+  if (variant != NBX_KERNEL_LDS && variant != NBX_KERNEL_SGPR && variant != NBX_KERNEL_SGPRW) variant = NBX_KERNEL_SGPRW;
+  if (o.fused_epilogue == 1 && variant == NBX_KERNEL_SGPRW && o.j_split == 1) variant = NBX_KERNEL_SGPR;
+  const int maxB = (c->precision == 32 && variant != NBX_KERNEL_SGPRW) ? 8 : 4;
   int B = o.bodies_per_lane;
   if (B != 1 && B != 2 && B != 4 && B != 8) B = 0;
   if (B > maxB) B = maxB;
-  if (B == 0) {
-    B = 4;
-    // short i ranges: keep at least ~64 i-blocks so the split count stays moderate
-    while (B > 2 && ceil_div(c->i_count, kBlock * B) < 16) B /= 2;
-  }
+  if (B == 0) B = c->i_count >= 16384 ? 4 : 2;
+  const int iblk = (variant == NBX_KERNEL_SGPRW ? 64 : kBlock) * B;  // bodies per workgroup
+  // j-range granularity of one split: a whole LDS tile / two pipelined SGPR batches (per wave)
+  const int gran = variant == NBX_KERNEL_LDS ? kTile : (variant == NBX_KERNEL_SGPRW ? 32 : 16);
+  const int max_split = std::max(1, c->n_alloc / gran);
   int S = o.j_split;
   if (S <= 0) {
-    const int bi = ceil_div(c->i_count, kBlock * B);
-    S = ceil_div(target_wgs, bi);
-    // the S partial-acceleration slabs are written and re-read every step: keep them small
-    // next to the pair work (<= 64 splits, <= 256 MiB)
-    S = std::min(S, 64);
+    const int bi = ceil_div(c->i_count, iblk);
+    S = std::min(32, ceil_div(target_wgs, bi));
+    // the S partial-acceleration slabs are written and re-read every step: keep them <= 256 MiB
     while (S > 1 && (size_t)S * c->own_pad * c->rec > ((size_t)256 << 20)) S /= 2;
   }
   S = std::max(1, std::min(S, max_split));
-  int jps = round_up(ceil_div(c->n_alloc, S), kTile);
+  int jps = round_up(ceil_div(c->n_alloc, S), gran);
   S = ceil_div(c->n_alloc, jps);  // drop empty tail splits
   c->B = B;
   c->S = S;
   c->jps = jps;
   c->math = (c->precision == 32 && B >= 2) ? MATH_PACKED : MATH_SCALAR;
-  c->variant = o.kernel_variant == NBX_KERNEL_LDS ? NBX_KERNEL_LDS : NBX_KERNEL_SGPR;
-  // fused_epilogue: 0 auto, 1 on, 2 off; only possible without a j-split
-  c->fused = (S == 1 && o.fused_epilogue != 2) ? 1 : 0;
-  c->grid = dim3(ceil_div(c->i_count, kBlock * B), S);
+  c->variant = variant;
+  // fused_epilogue: 0 auto, 1 on, 2 off; only without a j-split and not for the wave-split kernel
+  c->fused = (S == 1 && o.fused_epilogue != 2 && variant != NBX_KERNEL_SGPRW) ? 1 : 0;
+  c->grid = dim3(ceil_div(c->i_count, iblk), S);
 }
 
 template <typename T>
@@ -201,6 +208,33 @@ int enqueue_step(nbx_ctx* c, double dt) {
 
 int enqueue_step_any(nbx_ctx* c, double dt) {
   return c->precision == 32 ? enqueue_step<float>(c, dt) : enqueue_step<double>(c, dt);
+}
+
+// A window of `unit` (even) steps captured once per buffer parity and replayed: the two launches of a
+// step cost ~3.5 us each from the host but ~1.5 us as graph nodes (MI355X_MICROARCH.md, rows
+// 'boundary' / 'graph-replay-floor'), which is what bounds n <= 16k.
+int graph_unit_exec(nbx_ctx* c, int unit, double dt, hipGraphExec_t* out) {
+  for (auto& g : c->graphs)
+    if (g.steps == unit && g.parity == c->cur && g.dt == dt) { *out = g.exec; return NBX_OK; }
+  const int cur0 = c->cur;
+  hipGraph_t graph = nullptr;
+  HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  int rc = NBX_OK;
+  for (int s = 0; s < unit && rc == NBX_OK; ++s) {
+    rc = enqueue_step_any(c, dt);
+    c->cur ^= 1;
+  }
+  c->cur = cur0;
+  hipError_t e = hipStreamEndCapture(c->stream, &graph);
+  if (rc != NBX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+  if (e != hipSuccess) return fail(NBX_ERR_DEVICE, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) return fail(NBX_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+  c->graphs.push_back({unit, cur0, dt, exec});
+  *out = exec;
+  return NBX_OK;
 }
 
 int ensure_ke_cap(nbx_ctx* c, int need) {
@@ -373,9 +407,15 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
     c->own_stream = true;
   }
   auto_shape(c, o);
-  if (o.use_graph) { /* reserved: windows are enqueued as plain launches in this version */ }
+  // use_graph: 0 auto (launch-bound sizes only: < ~0.3 ms of pair work per step), 1 on, 2 off;
+  // capture needs a stream of our own
+  {
+    const double pairs = (double)c->i_count * (double)c->n;
+    c->use_graph = c->own_stream && (o.use_graph == 1 || (o.use_graph == 0 && pairs < 1.5e9));
+  }
 
-  const size_t pos_bytes = c->rec * (size_t)c->n_alloc;
+  // + spare records: the pipelined SGPR loop requests one batch past the last split (never used)
+  const size_t pos_bytes = c->rec * (size_t)(c->n_alloc + kSgprOverread);
   CREATE_TRY(hipMalloc(&c->posm[0], pos_bytes));
   CREATE_TRY(hipMalloc(&c->posm[1], pos_bytes));
   CREATE_TRY(hipMalloc(&c->velm, c->rec * (size_t)c->own_pad));
@@ -402,6 +442,7 @@ void nbx_destroy(nbx_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);  // NULL = the default stream when the caller lent us that one
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
   if (c->posm[0]) (void)hipFree(c->posm[0]);
   if (c->posm[1]) (void)hipFree(c->posm[1]);
   if (c->velm) (void)hipFree(c->velm);
@@ -443,7 +484,24 @@ static int step_common(nbx_ctx* c, double dt, int32_t nsteps, double* ke_last, d
     rc = ensure_ke_cap(c, std::max(nsteps, 1));
     if (rc) return rc;
   }
-  for (int s = 0; s < nsteps; ++s) {
+  int first = 0;
+  if (c->use_graph && !ke_trace && !c->profiling && nsteps >= 4) {
+    const int unit = std::min(nsteps & ~1, 20);
+    hipGraphExec_t exec = nullptr;
+    rc = graph_unit_exec(c, unit, dt, &exec);
+    if (rc) return rc;
+    while (nsteps - first >= unit) {  // an even unit leaves the buffer parity unchanged
+      HIP_TRY(hipGraphLaunch(exec, c->stream));
+      first += unit;
+      c->steps_done += unit;
+      c->graph_replays += 1;
+    }
+    if (first == nsteps && ke_last) {  // the partials of the last captured step are in ke_part
+      rc = enqueue_ke_reduce(c, 0);
+      if (rc) return rc;
+    }
+  }
+  for (int s = first; s < nsteps; ++s) {
     rc = enqueue_step_any(c, dt);
     if (rc) return rc;
     c->cur ^= 1;
@@ -602,6 +660,8 @@ int nbx_stats(nbx_ctx* c, nbx_stats_t* s) {
   s->force_launches_timed = c->force_timed;
   s->force_ms_total = c->force_ms_total;
   s->pairs_per_launch = (double)c->i_count * (double)c->n;
+  s->graph_replays = c->graph_replays;
+  s->use_graph = c->use_graph ? 1 : 0;
   // some boxes report an empty marketing name; fall back to / append the ISA name
   std::snprintf(s->device_name, sizeof(s->device_name), "%s%s%s", c->prop.name, c->prop.name[0] ? " " : "",
                 c->prop.gcnArchName);

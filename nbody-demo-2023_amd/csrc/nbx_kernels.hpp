@@ -136,12 +136,48 @@ struct ForceArgs {
   typename V4<T>::type* posm_next;   // FUSED: next position buffer (owned slice written)
   double* ke_part;                   // FUSED: one partial per workgroup
   int i_begin, i_count, own_pad;
-  int j_per_split;                   // multiple of kTile; split y covers [y*jps, min((y+1)*jps, n_alloc))
+  int j_per_split;                   // split y covers [y*jps, min((y+1)*jps, n_alloc)); multiple of kTile for the
+                                     // LDS source, of 2*kSgprBatch (x4 under WSPLIT) for the SGPR source
   int n_alloc;                       // multiple of kTile
   T dt;
 };
 
 enum : int { JSRC_LDS = 1, JSRC_SGPR = 2 };
+// records per scalar-load batch of the SGPR source (one s_load_dwordx16 = 64 B); a split's j range
+// (a quarter of it under WSPLIT) must be a multiple of this
+template <typename T> constexpr int kSgprBatch = 64 / (4 * (int)sizeof(T));
+constexpr int kSgprOverread = 16;  // spare records behind posm[n_alloc): the pipelined loop reads one batch ahead
+
+// One 64-byte batch of j records held in 16 SGPRs, loaded by an asm s_load_dwordx16 the compiler cannot
+// sink.  load() only requests; wait() is the first point at which the values may be read.
+template <typename T> struct SgprBatch;
+template <> struct SgprBatch<float> {
+  typedef float v16 __attribute__((ext_vector_type(16)));
+  v16 r;
+  __device__ __forceinline__ void load_first(const void* p) {
+    // s_nop: the address may have been produced by v_readfirstlane just before (VALU-written SGPR -> SMEM)
+    asm volatile("s_nop 4\n\ts_load_dwordx16 %0, %1, 0x0" : "=s"(r) : "s"(p));
+  }
+  __device__ __forceinline__ void load(const void* p) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(r) : "s"(p)); }
+  __device__ __forceinline__ void wait() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); }
+  __device__ __forceinline__ float x(int u) const { return r[4 * u]; }
+  __device__ __forceinline__ float y(int u) const { return r[4 * u + 1]; }
+  __device__ __forceinline__ float z(int u) const { return r[4 * u + 2]; }
+  __device__ __forceinline__ float w(int u) const { return r[4 * u + 3]; }
+};
+template <> struct SgprBatch<double> {
+  typedef double v8 __attribute__((ext_vector_type(8)));
+  v8 r;
+  __device__ __forceinline__ void load_first(const void* p) {
+    asm volatile("s_nop 4\n\ts_load_dwordx16 %0, %1, 0x0" : "=s"(r) : "s"(p));
+  }
+  __device__ __forceinline__ void load(const void* p) { asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(r) : "s"(p)); }
+  __device__ __forceinline__ void wait() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); }
+  __device__ __forceinline__ double x(int u) const { return r[4 * u]; }
+  __device__ __forceinline__ double y(int u) const { return r[4 * u + 1]; }
+  __device__ __forceinline__ double z(int u) const { return r[4 * u + 2]; }
+  __device__ __forceinline__ double w(int u) const { return r[4 * u + 3]; }
+};
 enum : int { MATH_SCALAR = 0, MATH_PACKED = 1 };
 
 // The B i-bodies a lane keeps in registers, and how one j record is applied to them.
@@ -177,27 +213,42 @@ struct IBodies<float, B, MATH_PACKED> {
 };
 
 // ---------------------------------------------------------------------------------------------
-// force_kernel: grid (ceil(i_count / (256*B)), S), block 256.
-// Lane t of workgroup bx owns bodies  i_begin + bx*256*B + b*256 + t,  b = 0..B-1  (coalesced).
+// force_kernel: block 256 = 4 wave64.
+//   WSPLIT == false: grid (ceil(i_count / (256*B)), S).  Lane t of workgroup bx owns bodies
+//     i_begin + bx*256*B + b*256 + t, b = 0..B-1, and every wave walks the whole j range of split y.
+//   WSPLIT == true (small n, SGPR source only): grid (ceil(i_count / (64*B)), S).  The four waves own
+//     the SAME 64*B bodies (lane l: bx*64*B + b*64 + l) and each walks one quarter of the split's
+//     j range; the four partial sums are added in wave order through LDS.  Four times the workgroups
+//     for the same number of partial-acceleration slabs.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int B, int JSRC, bool FUSED, int MINW, int MATH = MATH_SCALAR>
+template <typename T, int B, int JSRC, bool FUSED, int MINW, int MATH = MATH_SCALAR, bool WSPLIT = false>
 __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> a) {
   using T4 = typename V4<T>::type;
+  static_assert(!WSPLIT || (JSRC == JSRC_SGPR && !FUSED), "wave split exists for the unfused SGPR kernel only");
   const int t = threadIdx.x;
-  const int base = blockIdx.x * (kBlock * B) + t;
+  constexpr int kStride = WSPLIT ? 64 : kBlock;  // distance between a lane's consecutive bodies
+  const int base = blockIdx.x * (kStride * B) + (WSPLIT ? (t & 63) : t);
 
   IBodies<T, B, MATH> ib;
 #pragma unroll
   for (int b = 0; b < B; ++b) {
-    int li = base + b * kBlock;
+    int li = base + b * kStride;
     li = li < a.i_count ? li : a.i_count - 1;  // padded lanes shadow the last owned body
     const T4 p = a.posm[a.i_begin + li];
     ib.set(b, p.x, p.y, p.z);
   }
 
-  const int j0 = blockIdx.y * a.j_per_split;
+  int j0 = blockIdx.y * a.j_per_split;
   int j1 = j0 + a.j_per_split;
   j1 = j1 < a.n_alloc ? j1 : a.n_alloc;
+  if constexpr (WSPLIT) {
+    // wave-uniform quarter of [j0, j1); quarter length is a multiple of the load batch
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int q = a.j_per_split >> 2;
+    j0 += wave * q;
+    const int e = j0 + q;
+    j1 = e < j1 ? e : j1;
+  }
 
   if constexpr (JSRC == JSRC_LDS) {
     __shared__ T4 tile[2][kTile];
@@ -219,18 +270,69 @@ __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> 
       cur ^= 1;
     }
   } else {
-    const T4* __restrict__ pj_ptr = a.posm;
-    constexpr int U = (sizeof(T) == 4) ? 8 : 4;
-    for (int j = j0; j < j1; j += U) {
+    // Wave-uniform j index => the records travel by s_load_dwordx16 (64 B = kSgprBatch records) into
+    // SGPRs and feed the VALU as scalar operands: no LDS bandwidth, no VGPRs, no barrier.  Two
+    // register batches ping-pong: the load of the NEXT batch is issued before the current one is
+    // consumed, so the scalar-cache latency sits under ~200 VALU instructions even when a SIMD holds
+    // a single wave (small n).  hipcc would sink a plain C++ prefetch back to its use, so the loads
+    // are asm statements (guide section 5.7 form (ii): "=s" load, later a wait naming the destination
+    // "+s"; SMEM returns out of order, hence lgkmcnt(0)).  The final trip over-reads one batch past
+    // the split; the array carries kSgprOverread spare records for the last split.
+    constexpr int U = kSgprBatch<T>;
+    const char* p = reinterpret_cast<const char*>(a.posm + j0);
+    if (j0 < j1) {
+      SgprBatch<T> ba;
+      ba.load_first(p);
+      ba.wait();
+      // Invariant at the loop head AND at the back edge: `ba` has landed.  No asm-loaded value is
+      // in flight across the back edge, so a register copy the compiler may insert for the loop-carried
+      // value can never read (or be overtaken by) a pending scalar load.  tests/test_isa_audit.py checks
+      // the compiled code: nothing touches a batch's SGPRs between its s_load and its s_waitcnt.
+      for (int j = j0; j < j1; j += 2 * U) {
+        SgprBatch<T> bb;
+        bb.load(p + 64);
+        __builtin_amdgcn_sched_barrier(0);  // keep the arithmetic below the request (no operand ties it)
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const T4 pj = pj_ptr[j + u];  // wave-uniform index: s_load into SGPRs
-        ib.apply(pj.x, pj.y, pj.z, pj.w);
+        for (int u = 0; u < U; ++u) ib.apply(ba.x(u), ba.y(u), ba.z(u), ba.w(u));
+        __builtin_amdgcn_sched_barrier(0);
+        bb.wait();
+        ba.load(p + 128);  // next trip's first batch; over-reads 64 B past the split on the last trip
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) ib.apply(bb.x(u), bb.y(u), bb.z(u), bb.w(u));
+        __builtin_amdgcn_sched_barrier(0);
+        ba.wait();
+        p += 128;
       }
     }
   }
 
-  if constexpr (!FUSED) {
+  if constexpr (WSPLIT) {
+    __shared__ T red[3][3][B][64];  // [wave-1][component][body][lane]
+    const int lane = t & 63, wave = t >> 6;
+    if (wave > 0) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        T x, y, z;
+        ib.get(b, x, y, z);
+        red[wave - 1][0][b][lane] = x; red[wave - 1][1][b][lane] = y; red[wave - 1][2][b][lane] = z;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      T4* out = a.accp + (size_t)blockIdx.y * a.own_pad;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int li = base + b * kStride;
+        T4 r;
+        ib.get(b, r.x, r.y, r.z);
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { r.x += red[w][0][b][lane]; r.y += red[w][1][b][lane]; r.z += red[w][2][b][lane]; }
+        r.w = (T)0;
+        if (li < a.i_count) out[li] = r;
+      }
+    }
+  } else if constexpr (!FUSED) {
     T4* out = a.accp + (size_t)blockIdx.y * a.own_pad;
 #pragma unroll
     for (int b = 0; b < B; ++b) {

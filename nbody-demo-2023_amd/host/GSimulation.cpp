@@ -46,8 +46,10 @@ real_type* alloc_array(int n) {
 GSimulation::GSimulation()
     : particles(NULL), _kenergy(0), _totTime(0), _totFlops(0), _cpu_ratio(0.f), _thread_dim0(0),
       _thread_dim1(0), _devices(2), _allocated(false), _alloc_n(0) {
+#ifndef NBX_BANNER_IN_MAIN  // ver7 prints the banner here (ver7/GSimulation.cpp:26-27), ver5_all in main()
   std::cout << "===============================" << std::endl;
   std::cout << " Initialize Gravity Simulation" << std::endl;
+#endif
   set_npart(2000);
   set_nsteps(500);
   set_tstep(0.1);
@@ -144,6 +146,7 @@ void GSimulation::start() {
   const char* kv = std::getenv("NBODY_KERNEL");
   if (kv && !std::strcmp(kv, "sgpr")) opts.kernel_variant = NBX_KERNEL_SGPR;
   if (kv && !std::strcmp(kv, "lds")) opts.kernel_variant = NBX_KERNEL_LDS;
+  if (kv && !std::strcmp(kv, "sgprw")) opts.kernel_variant = NBX_KERNEL_SGPRW;
 
   nbx_ctx* ctx = NULL;
   if (nbx_create(&ctx, n, kPrecisionBits, &opts)) die_nbx("nbx_create");
@@ -206,8 +209,9 @@ void GSimulation::start() {
   std::cout << "===============================" << std::endl;
   // extra lines AFTER the reference's footer, so line-wise diffs of the reference part still match
   std::cout << "# Device             : " << st.device_name << " (" << st.cu_count << " CUs), fp" << st.precision
-            << ", bodies/lane " << st.bodies_per_lane << ", j-split " << st.j_split << ", j-tile " << st.j_tile
-            << std::endl;
+            << ", kernel " << (st.kernel_variant == NBX_KERNEL_LDS ? "lds" : st.kernel_variant == NBX_KERNEL_SGPR ? "sgpr" : "sgprw")
+            << ", bodies/lane " << st.bodies_per_lane << ", j-split " << st.j_split << ", grid " << st.force_grid_x << "x"
+            << st.force_grid_y << std::endl;
   if (nf > 2) {
     const double pairs_per_s = av / 29.0 * 1e9;  // GFlops(29/pair) -> pair/s, integration term ignored
     std::cout << "# Pair rate          : " << pairs_per_s * 1e-9 << " G pair/s = "

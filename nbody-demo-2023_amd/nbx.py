@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NBX_LIB") or os.path.join(_HERE, "libnbx.so")
 
 NBX_OK, NBX_ERR_ARG, NBX_ERR_DEVICE, NBX_ERR_STATE, NBX_ERR_ALLOC = 0, -1, -2, -3, -4
-KERNEL_AUTO, KERNEL_LDS, KERNEL_SGPR = 0, 1, 2
+KERNEL_AUTO, KERNEL_LDS, KERNEL_SGPR, KERNEL_SGPRW = 0, 1, 2, 3
 
 # every symbol include/nbx.h declares (tests check the library exports each of them)
 SYMBOLS = (
@@ -50,6 +50,7 @@ class Stats(ctypes.Structure):
         ("cu_count", ctypes.c_int32), ("clock_mhz", ctypes.c_int32), ("steps_done", ctypes.c_int64),
         ("force_launches_timed", ctypes.c_int64), ("force_ms_total", ctypes.c_double),
         ("pairs_per_launch", ctypes.c_double), ("device_name", ctypes.c_char * 64),
+        ("graph_replays", ctypes.c_int64), ("use_graph", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
     def asdict(self):

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Pair-rate sweep n = 2048 * 2^k (2k ... 1M) on one GPU: the table north_star asks for
+(absolute pair/s and fraction of the fp32 vector-FMA roofline), plus P logical ranks on the one device
+(same partition/exchange code path as the multi-GPU run, exchange by device-to-device copies).
+
+usage: python scripts/sweep.py [--out profiles/r01_sweep.json] [--max-n 1048576] [--precision 32]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "nbody-demo-2023_amd"))
+import nbx  # noqa: E402
+
+PEAK = {32: 157.3e12, 64: 78.6e12}
+
+
+def time_steps(n, precision, target_s=1.0):
+    ic = nbx.initial_conditions(n, precision)
+    with nbx.Context(n, precision) as c:
+        c.upload(ic)
+        c.step(3, kenergy=False)
+        c.sync()
+        t0 = time.perf_counter()
+        c.step(2, kenergy=False)
+        c.sync()
+        per = (time.perf_counter() - t0) / 2
+        steps = max(5, min(2000, int(target_s / max(per, 1e-6))))
+        c.profile(True)
+        t0 = time.perf_counter()
+        c.step(steps, kenergy=False)
+        c.sync()
+        wall = time.perf_counter() - t0
+        st = c.stats()
+    kms = st["force_ms_total"] / max(1, st["force_launches_timed"])
+    return {"n": n, "steps": steps, "us_per_step": 1e6 * wall / steps, "pair_per_s": float(n) * n * steps / wall,
+            "roofline_frac": 20.0 * float(n) * n * steps / wall / PEAK[precision],
+            "force_kernel_us": 1e3 * kms, "force_kernel_frac": 20.0 * float(n) * n / (kms * 1e-3) / PEAK[precision] if kms else None,
+            "bodies_per_lane": st["bodies_per_lane"], "j_split": st["j_split"], "grid": [st["force_grid_x"], st["force_grid_y"]],
+            "kernel": {1: "lds", 2: "sgpr", 3: "sgprw"}[st["kernel_variant"]]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sweep.json"))
+    ap.add_argument("--max-n", type=int, default=1048576)
+    ap.add_argument("--precision", type=int, default=32)
+    a = ap.parse_args()
+    rows = []
+    n = 2048
+    print("%9s %8s %12s %14s %9s %12s %9s  shape" % ("n", "steps", "us/step", "G pair/s", "roof %", "kernel us", "kern %"))
+    while n <= a.max_n:
+        r = time_steps(n, a.precision)
+        rows.append(r)
+        print("%9d %8d %12.1f %14.1f %9.2f %12.1f %9.2f  %s B%d S%d %dx%d" % (
+            r["n"], r["steps"], r["us_per_step"], r["pair_per_s"] * 1e-9, 100 * r["roofline_frac"], r["force_kernel_us"],
+            100 * (r["force_kernel_frac"] or 0), r["kernel"], r["bodies_per_lane"], r["j_split"], r["grid"][0], r["grid"][1]), flush=True)
+        n *= 2
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump({"precision": a.precision, "peak_flops": PEAK[a.precision], "flop_per_pair": 20, "rows": rows}, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+"""CPU-side audit of the compiled gfx950 code (hipcc cross-compiles without a GPU).
+
+The SGPR j-source issues its scalar loads from asm statements, which hipcc neither counts nor waits
+for (cdna_hip_programming.md section 5.7).  A compiler-inserted copy or a reuse of a batch's SGPRs
+between the s_load and its s_waitcnt is silent corruption -- or a memory fault when the late data
+lands in a register that meanwhile holds an address (this happened once: DESIGN.md section 3.1).
+This test disassembles every force_kernel instance and proves that cannot happen.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+SRC = os.path.join(ROOT, "nbody-demo-2023_amd", "csrc", "nbx_api.hip")
+
+
+@pytest.fixture(scope="module")
+def kernels(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "nbx_api.s"
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", SRC, "-o", str(out)])
+    txt = open(out).read()
+    ks = {}
+    for m in re.finditer(r"\n(_ZN3nbx\w+):(.*?)\n\s+s_endpgm.*?\.amdhsa_kernel \1(.*?)\.end_amdhsa_kernel", txt, re.S):
+        ks[m.group(1)] = (m.group(2), m.group(3))
+    # epilogue blocks after the first s_endpgm belong to the same function: take up to .Lfunc_end instead
+    for m in re.finditer(r"\n(_ZN3nbx\w+):(.*?)\.Lfunc_end", txt, re.S):
+        if m.group(1) in ks:
+            ks[m.group(1)] = (m.group(2), ks[m.group(1)][1])
+    return ks
+
+
+def _sregs(operand_text):
+    regs = set()
+    for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", operand_text):
+        regs.update(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bs(\d+)\b", operand_text):
+        regs.add(int(a))
+    return regs
+
+
+def test_every_force_kernel_instance_is_present(kernels):
+    names = [k for k in kernels if "force_kernel" in k]
+    assert len(names) >= 40, len(names)
+    assert any("integrate_kernel" in k for k in kernels) and any("ke_reduce_kernel" in k for k in kernels)
+
+
+def test_no_scratch_no_spills(kernels):
+    for name, (_, desc) in kernels.items():
+        m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", desc)
+        assert m and int(m.group(1)) == 0, name
+
+
+def test_asm_scalar_loads_are_never_touched_before_their_wait(kernels):
+    checked = 0
+    for name, (body, _) in kernels.items():
+        if "force_kernel" not in name:
+            continue
+        pending = {}  # sgpr -> line of the asm load that will write it
+        in_asm = False
+        for ln, line in enumerate(body.split("\n")):
+            t = line.strip()
+            if t.startswith(";;#ASMSTART") or t.startswith("; ;#ASMSTART") or "#ASMSTART" in t:
+                in_asm = True
+                continue
+            if "#ASMEND" in t:
+                in_asm = False
+                continue
+            if not t or t.startswith(";") or t.startswith("."):
+                continue
+            t = t.split(";")[0].strip()
+            if not t:
+                continue
+            if re.match(r"s_waitcnt\b.*lgkmcnt\(0\)", t) or t == "s_waitcnt lgkmcnt(0)":
+                pending.clear()
+                continue
+            ops = t.split(None, 1)[1] if " " in t or "\t" in t else ""
+            if in_asm and t.startswith("s_load_dwordx16"):
+                dst = ops.split(",")[0]
+                rest = ",".join(ops.split(",")[1:])
+                assert not (_sregs(rest) & set(pending)), (name, ln, t)
+                for r in _sregs(dst):
+                    assert r not in pending, (name, ln, t)
+                    pending[r] = ln
+                checked += 1
+                continue
+            if re.match(r"s_(cbranch|branch|endpgm|barrier|nop|waitcnt|setprio|sleep)", t) or t.endswith(":"):
+                continue
+            touched = _sregs(ops)
+            bad = touched & set(pending)
+            assert not bad, "%s: line %d `%s` touches s%s while the scalar load issued at line %d is in flight" % (
+                name, ln, t, sorted(bad), min(pending[r] for r in bad))
+    assert checked >= 40, checked
+
+
+def test_sgpr_source_really_uses_scalar_loads_and_lds_source_broadcast_reads(kernels):
+    for name, (body, _) in kernels.items():
+        m = re.search(r"force_kernelI[fd]Li\dELi([12])E", name)
+        if not m:
+            continue
+        if m.group(1) == "2":
+            assert body.count("s_load_dwordx16") >= 3, name      # prologue + two pipelined requests per trip
+        else:
+            assert body.count("ds_read_b128") + body.count("ds_read2_b64") >= 8, name  # unrolled broadcast reads of the tile
+            assert "s_load_dwordx16" not in body, name
+
+
+def test_hot_loop_uses_raw_rsq_and_packed_math(kernels):
+    for name, (body, _) in kernels.items():
+        if "force_kernelIf" not in name:
+            continue
+        assert "v_rsq_f32" in body and "v_div_scale" not in body and "v_sqrt_f32" not in body, name
+        if re.search(r"force_kernelIfLi[248]ELi\dELb[01]ELi1ELi1E", name):  # MATH_PACKED instances
+            assert "v_pk_fma_f32" in body and "v_pk_mul_f32" in body, name

@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
   for (auto& p : h) { p.x = U(g); p.y = U(g); p.z = U(g); p.w = 6.67259e-11f * n * U(g); }
   float4 *posm, *accp;
   const int maxS = 128;
-  CK(hipMalloc(&posm, sizeof(float4) * n));
+  CK(hipMalloc(&posm, sizeof(float4) * (n + 16)));
   CK(hipMalloc(&accp, sizeof(float4) * (size_t)n * maxS));
   CK(hipMemcpy(posm, h.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
   hipStream_t st;
@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
   reg_slp(base);
   for (auto& b : base)
     for (int S : splits) {
-      if (S > n / kTile) continue;
+      if (S > n / (b.B < 0 ? 64 : kTile)) continue;
       Variant v = b;
       v.S = S;
       v.name += " S" + std::to_string(S);
@@ -75,10 +75,14 @@ int main(int argc, char** argv) {
   std::vector<float4> ref(n), got(n);
   auto run = [&](Variant& v, bool timeit) {
     KbArgs a{posm, accp, n, 0};
-    int jps = (n / v.S + kTile - 1) / kTile * kTile;
+    const bool ws = v.B < 0;
+    const int Bv = ws ? -v.B : v.B;
+    const int gran = ws ? 64 : kTile;  // WSPLIT: quarter of jps must be a multiple of 16
+    int jps = (n / v.S + gran - 1) / gran * gran;
     a.jps = jps;
     int S = (n + jps - 1) / jps;
-    dim3 grid((n + kBlock * v.B - 1) / (kBlock * v.B), S);
+    const int ib = ws ? 64 * Bv : kBlock * Bv;
+    dim3 grid((n + ib - 1) / ib, S);
     if (timeit) CK(hipEventRecord(e0, st));
     v.launch(a, grid, st);
     if (timeit) {
