@@ -158,13 +158,18 @@ def main():
     import nbx
     import sharded
 
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     # NBX_BENCH_FORCE_DIST=1 rehearses the RCCL path with a 1-rank group (the only way to run it on a 1-GPU box)
     force_dist = bool(os.environ.get("NBX_BENCH_FORCE_DIST")) and "RANK" in os.environ
     use_dist = world > 1 or force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # NBX_BENCH_BACKEND=gloo: rehearsal of the N>1 code path with several ranks sharing one GPU
+        backend = os.environ.get("NBX_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     opts = dict(bodies_per_lane=a.bodies_per_lane, j_split=a.j_split,
                 kernel_variant={"auto": 0, "lds": 1, "sgpr": 2, "sgprw": 3}[a.kernel])
 
@@ -190,7 +195,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = sim.engine.ctx.stats()

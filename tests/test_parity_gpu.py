@@ -395,3 +395,98 @@ def test_product_engine_under_torch_distributed(nbx, tmp_path, world, backend):
         assert r["pos_x"] == px.tolist()[:64] + px.tolist()[-64:]
         assert rel_err(r["ke"], ke).max() < 1e-12
     assert sum(r["i_count"] for r in res) == n
+
+
+# ---- T6: the drop-in executables -----------------------------------------------------------------
+def _run_cli(exe, *args):
+    import subprocess
+    path = os.path.join(ROOT, "nbody-demo-2023_amd", "host", exe)
+    p = subprocess.run([path] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    return p.returncode, p.stdout.splitlines(), p.stderr
+
+
+def _rows(lines):
+    import re
+    out = []
+    for ln in lines:
+        m = re.match(r"^ (\d+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)\s*$", ln)
+        if m:
+            out.append(m.groups())
+    return out
+
+
+def test_cli_default_run_prints_the_reference_table():
+    """`./nbody.x` (no arguments) = the reference's default 2000 x 500: same frame, same 5-digit kenergy column
+    as the unmodified ver7 binary prints, 0 exit status."""
+    rc, lines, _ = _run_cli("nbody.x")
+    assert rc == 0
+    assert lines[0] == "=" * 31 and lines[1] == " Initialize Gravity Simulation"
+    assert lines[2] == " nPart = 2000; nSteps = 500; dt = 0.1"
+    assert lines[3] == "-" * 48 and lines[5] == "-" * 48
+    assert lines[4] == " " + "s".ljust(8) + "dt".ljust(8) + "kenergy".ljust(12) + "time (s)".ljust(12) + "GFlops".ljust(12)
+    rows = _rows(lines)
+    assert [r[0] for r in rows] == [str(s) for s in range(50, 501, 50)]
+    assert [r[1] for r in rows] == ["5", "10", "15", "20", "25", "30", "35", "40", "45", "50"]
+    assert [r[2] for r in rows] == ["0.1432", "2.4341", "8.1256", "17.877", "32.966", "55.786", "91.132", "150.12", "264.78", "571.53"]
+    assert all(len(ln) == 53 for ln in lines[6:16])              # 1 + 8 + 8 + 12 + 12 + 12, left aligned
+    i = lines.index("", 16)
+    assert lines[i + 1].startswith("# Number Threads     : ")
+    assert lines[i + 2].startswith("# Total Time (s)     : ")
+    assert lines[i + 3].startswith("# Average Perfomance : ") and " +- " in lines[i + 3]
+    assert lines[i + 4] == "=" * 31
+    assert lines[i + 5].startswith("# Device") and lines[i + 6].startswith("# Pair rate")
+
+
+def test_cli_argument_quirks_of_ver7_main():
+    # one argument: particles only; three arguments: the step count is silently ignored (argc == 3 test, ver7/main.cpp:36)
+    rc, lines, _ = _run_cli("nbody.x", 1000)
+    assert rc == 0 and lines[2] == " nPart = 1000; nSteps = 500; dt = 0.1"
+    rc, lines, _ = _run_cli("nbody.x", 1000, 100, "extra")
+    assert rc == 0 and lines[2] == " nPart = 1000; nSteps = 500; dt = 0.1"
+    rc, lines, _ = _run_cli("nbody.x", 1000, 120)
+    rows = _rows(lines)
+    assert rc == 0 and [r[0] for r in rows] == ["50", "100"]       # trailing 20 steps run, not printed
+    assert any("nan" in ln for ln in lines if ln.startswith("# Average"))  # nf <= 2: the reference prints nan too
+    g = load_golden("ver7_f32_n1000_s100.json")
+    assert rows[1][2] == "%.5g" % np.float32(g["kenergy"][99])
+
+
+def test_cli_fp64_and_ver5_front_end():
+    rc, lines, _ = _run_cli("nbody_fp64.x", 2000, 100)
+    g = load_golden("ver7_f64_n2000_s500.json")
+    rows = _rows(lines)
+    assert rc == 0 and rows[1][2] == "%.5g" % g["kenergy"][99] and rows[0][2] == "%.5g" % g["kenergy"][49]
+    rc, lines, err = _run_cli("nbody_v5.x", 2000, 100, "gpu", 0.5, 256, 2)
+    assert rc == 0 and lines[0] == "gpu" and lines[1] == "=" * 31
+    assert _rows(lines)[1][2] == "2.4341"
+    assert any("bodies/lane 2" in ln for ln in lines)
+    rc, lines, err = _run_cli("nbody_v5.x", 2000, 100, "cpu")
+    assert rc == 1 and "no CPU engine" in err
+
+
+# ---- T8: bench.py contract and performance floor -------------------------------------------------
+def test_bench_line_schema_and_roofline_floor():
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-baseline", "port"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "pair-interactions/s" and d["unit"] == "pair/s" and d["n_gpus"] == 1 and d["steps"] == 5
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert "workload" in d["config"] and d["config"]["n_bodies"] == 262144
+    r = d["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r)
+    assert r["peak"] == 157.3 and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["launches_timed"] == 5
+    # value (whole step, wall clock) and the HIP-event kernel time must tell the same story
+    assert abs(d["value"] * 20e-12 / r["achieved"] - 1.0) < 0.05
+    assert r["frac"] > 0.40, r["frac"]                       # north_star target at n = 262144
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 1e8 and c["unit"] == "pair/s"
+    assert d["parity"]["max_rel_kenergy_err"] < 1e-4

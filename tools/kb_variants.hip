@@ -28,5 +28,8 @@ void KB_REGISTER(std::vector<Variant>& vs) {
   vs.push_back({std::string(KB_TAG) + " sgprW B1   ", -1, 0, launch_f32<1, JSRC_SGPR, 1, 0, true>, {}});
   vs.push_back({std::string(KB_TAG) + " sgprW B2 pk", -2, 0, launch_f32<2, JSRC_SGPR, 1, 1, true>, {}});
   vs.push_back({std::string(KB_TAG) + " sgprW B4 pk", -4, 0, launch_f32<4, JSRC_SGPR, 1, 1, true>, {}});
+  vs.push_back({std::string(KB_TAG) + " sgprW B6 pk", -6, 0, launch_f32<6, JSRC_SGPR, 1, 1, true>, {}});
+  vs.push_back({std::string(KB_TAG) + " sgprW B8 pk", -8, 0, launch_f32<8, JSRC_SGPR, 1, 1, true>, {}});
+  vs.push_back({std::string(KB_TAG) + " sgprW B4 sc", -4, 0, launch_f32<4, JSRC_SGPR, 1, 0, true>, {}});
 #endif
 }
