@@ -16,6 +16,7 @@
 
 #include "../../include/nbx.h"
 #include "cpu_time.hpp"
+#include "snapshot.hpp"
 
 namespace {
 
@@ -126,6 +127,15 @@ void GSimulation::start() {
   const double dt = (double)get_tstep();
 
   init();
+  // NBODY_RESTART=<file>: continue from a snapshot instead of the seed-42 initial conditions
+  long long steps_before = 0;
+  if (const char* rs = std::getenv("NBODY_RESTART")) {
+    std::string err;
+    if (n > 0 && !nbx_snapshot::load(rs, particles, n, &steps_before, &err)) {
+      std::cerr << "nbody.x: restart failed: " << err << std::endl;
+      std::exit(1);
+    }
+  }
   print_header();
 
   if (n <= 0) {  // the reference would run zero-trip loops; nothing to hand to the GPU
@@ -201,6 +211,14 @@ void GSimulation::start() {
     die_nbx("nbx_download");
   init_acc();
   nbx_destroy(ctx);
+  // NBODY_SNAPSHOT=<file>: keep the final state (the reference drops it at exit)
+  if (const char* sp = std::getenv("NBODY_SNAPSHOT")) {
+    std::string err;
+    if (!nbx_snapshot::save(sp, particles, n, steps_before + nsteps, &err)) {
+      std::cerr << "nbody.x: snapshot failed: " << err << std::endl;
+      std::exit(1);
+    }
+  }
 
   std::cout << std::endl;
   std::cout << "# Number Threads     : " << 1 << std::endl;

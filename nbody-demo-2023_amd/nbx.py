@@ -231,3 +231,15 @@ class Context:
         s = Stats()
         _check(self._L.nbx_stats(self._h, ctypes.byref(s)), "nbx_stats")
         return s.asdict()
+
+
+def read_snapshot(path):
+    """Read an NBXSNAP1 file written by nbody.x (NBODY_SNAPSHOT=...): returns (state dict, steps_done)."""
+    import struct
+    with open(path, "rb") as f:
+        magic, n, prec, steps = struct.unpack("<8siiq", f.read(24))
+        if magic != b"NBXSNAP1":
+            raise ValueError("%s is not an NBXSNAP1 snapshot" % path)
+        dt = _dtype(prec)
+        state = {k: np.frombuffer(f.read(n * dt().itemsize), dtype=dt).copy() for k in FIELDS}
+    return state, steps

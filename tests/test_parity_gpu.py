@@ -490,3 +490,30 @@ def test_bench_line_schema_and_roofline_floor():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 1e8 and c["unit"] == "pair/s"
     assert d["parity"]["max_rel_kenergy_err"] < 1e-4
+
+
+def test_cli_snapshot_and_restart(nbx, tmp_path):
+    """NBODY_SNAPSHOT / NBODY_RESTART: 100 + 100 steps through a snapshot file == 200 steps straight, bit for bit."""
+    import subprocess
+    exe = os.path.join(ROOT, "nbody-demo-2023_amd", "host", "nbody.x")
+    a, b, c = (str(tmp_path / x) for x in ("a.snap", "b.snap", "c.snap"))
+    run = lambda args, env: subprocess.run([exe] + args, env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert run(["3000", "100"], {"NBODY_SNAPSHOT": a}).returncode == 0
+    p2 = run(["3000", "100"], {"NBODY_RESTART": a, "NBODY_SNAPSHOT": b})
+    p3 = run(["3000", "200"], {"NBODY_SNAPSHOT": c})
+    assert p2.returncode == 0 and p3.returncode == 0
+    sb, nb_ = nbx.read_snapshot(b)
+    sc, nc_ = nbx.read_snapshot(c)
+    assert nb_ == nc_ == 200
+    for f in sb:
+        assert np.array_equal(sb[f], sc[f]), f
+    assert _rows(p2.stdout.splitlines())[-1][2] == _rows(p3.stdout.splitlines())[-1][2]
+    # the snapshot is what a context would download after the same steps
+    with nbx.Context(3000) as ctx:
+        ctx.upload(nbx.initial_conditions(3000))
+        ctx.step(200, kenergy=False)
+        d = ctx.download()
+    for f in d:
+        assert np.array_equal(d[f], sc[f]), f
+    bad = run(["2999", "10"], {"NBODY_RESTART": a})
+    assert bad.returncode == 1 and "snapshot holds 3000 bodies" in bad.stderr

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 passes of scripts/profile.sh into profiles/<tag>_*.{csv,json,md}.
 
-usage: python tools/roofline_summary.py gpurun_out/prof r01 [n] [gpus]
+usage: python tools/roofline_summary.py gpurun_out/prof r01 [n] [gpus] [precision]
 
 HBM-side bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are KiB per dispatch;
 on gfx950 FETCH_SIZE tallies the 128-B requests of wide (16 B/lane) coalesced reads at 64 B, so the
@@ -37,6 +37,9 @@ def main():
     src, tag = sys.argv[1], sys.argv[2]
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
     gpus = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    precision = int(sys.argv[5]) if len(sys.argv) > 5 else 32
+    rec = 16 if precision == 32 else 32
+    peak_flops = 20.0
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dst = os.path.join(root, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -75,7 +78,8 @@ def main():
         "counters_per_launch": counters,
         "hbm_side_read_bytes_per_launch": read_bytes, "hbm_side_write_bytes_per_launch": write_bytes,
         "hbm_bytes_per_launch": traffic,
-        "algorithmic_bytes_per_launch": 16.0 * n + 16.0 * (n / gpus) * 8,
+        "precision": precision,
+        "algorithmic_bytes_per_launch": float(rec) * n + float(rec) * (n / gpus) * 8,
         "effective_clock_ghz": clock_ghz,
         "valu_wave_insts_per_64_pairs": None if not valu_insts else valu_insts / (pairs / 64.0),
         "valu_busy_fraction": None,
@@ -88,8 +92,9 @@ def main():
     if traffic and avg_ms:
         summary["hbm_side_GBps"] = traffic / (avg_ms * 1e-3) * 1e-9
     json.dump(summary, open(os.path.join(dst, "%s_roofline_summary.json" % tag), "w"), indent=1)
-    if traffic:
-        json.dump({"n": n, "gpus": gpus, "hbm_bytes_per_launch": traffic, "source": "profiles/%s_roofline_summary.json" % tag},
+    if traffic and precision == 32:
+        json.dump({"n": n, "gpus": gpus, "precision": precision, "hbm_bytes_per_launch": traffic,
+                   "source": "profiles/%s_roofline_summary.json" % tag},
                   open(os.path.join(dst, "roofline_traffic.json"), "w"))
     print(json.dumps(summary, indent=1))
 
