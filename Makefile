@@ -14,7 +14,7 @@ $(PKG)/nbx_api.o: $(CSRC)/nbx_api.hip $(CSRC)/nbx_kernels.hpp include/nbx.h
 $(PKG)/nbx_ic.o: $(CSRC)/nbx_ic.cpp include/nbx.h
 	$(HIPCC) -O2 -std=c++17 -fPIC -Wall -ffp-contract=off -c $< -o $@
 $(PKG)/libnbx.so: $(PKG)/nbx_api.o $(PKG)/nbx_ic.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl
 
 host: lib
 	$(MAKE) -C $(PKG)/host

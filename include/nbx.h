@@ -152,6 +152,30 @@ int nbx_download(nbx_ctx* ctx, void* pos_x, void* pos_y, void* pos_z, void* vel_
                  void* vel_z);
 
 /*
+ * Single-process multi-GPU: one host thread drives `n_ranks` contexts, rank r on devices[r] owning the
+ * r-th i-block (block = ceil(n / n_ranks) rounded up to 256 records; the reference's MPI / OpenCL split,
+ * ver5_all/GSimulation.cpp:93-115, opencl/Compute.cpp:241-255).  Per time step: every rank's local step on
+ * its own stream, then ONE all-gather of the freshly integrated position blocks -- RCCL ncclAllGather
+ * (in place, grouped over the ranks; librccl is loaded on first use) when the devices are distinct, peer /
+ * device-to-device copies when `devices` repeats an ordinal (logical ranks on one GPU, used by the tests)
+ * or when RCCL cannot be loaded -- then commit.  Replaces mpi_bcast_all + mpi_gather_acc
+ * (ver5_all/GSimulation.cpp:170-214).  Kinetic energy: rank partials added on the host when asked for.
+ * devices == NULL: rank r -> device r % hipGetDeviceCount().  opts (nullable) supplies the launch-shape fields;
+ * its slice / stream / device fields are ignored.
+ */
+typedef struct nbx_group nbx_group;
+int nbx_group_create(nbx_group** out, int32_t n, int32_t precision, int32_t n_ranks, const int32_t* devices,
+                     const nbx_opts* opts);
+void nbx_group_destroy(nbx_group* g);
+int nbx_group_upload(nbx_group* g, const void* pos_x, const void* pos_y, const void* pos_z, const void* vel_x,
+                     const void* vel_y, const void* vel_z, const void* mass);
+int nbx_group_step(nbx_group* g, double dt, int32_t nsteps, double* kenergy_out);
+int nbx_group_download(nbx_group* g, void* pos_x, void* pos_y, void* pos_z, void* vel_x, void* vel_y, void* vel_z);
+/* ranks actually used (n_ranks is reduced so that no rank is empty), 1 if the exchange runs over RCCL, and the
+ * per-rank statistics of rank `rank`.  Any out pointer may be NULL. */
+int nbx_group_info(nbx_group* g, int32_t* n_ranks, int32_t* uses_rccl, int32_t rank, nbx_stats_t* rank_stats);
+
+/*
  * Seed-42 initial conditions of ver7/GSimulation.cpp:45-94, bit-exact and independent of the
  * host's libstdc++: mt19937(42) re-created per array family, libstdc++-11's
  * uniform_real_distribution<float> restated (one 32-bit draw per value).  Host-only (no GPU

@@ -6,8 +6,11 @@
 // No CPU fallback exists: without a HIP device every entry point fails with NBX_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -669,3 +672,249 @@ int nbx_stats(nbx_ctx* c, nbx_stats_t* s) {
 }
 
 }  // extern "C"
+
+// =============================================================================================
+// nbx_group: single-process multi-GPU driver (see include/nbx.h)
+// =============================================================================================
+namespace {
+
+// The five RCCL entry points used, resolved at run time so libnbx.so has no link-time dependency on
+// librccl (and binds to the copy already in the process when a host such as PyTorch brought its own).
+struct Rccl {
+  typedef void* comm_t;
+  int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(comm_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int /*ncclDataType_t*/, comm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+  bool load() {
+    if (ok) return true;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return false;
+    CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+    GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+    AllGather = (decltype(AllGather))dlsym(h, "ncclAllGather");
+    GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+    ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && AllGather;
+    return ok;
+  }
+};
+Rccl g_rccl;
+constexpr int kNcclChar = 0;  // ncclInt8 / ncclChar (rccl.h)
+
+}  // namespace
+
+struct nbx_group {
+  int n = 0, precision = 32, P = 0, block = 0, n_alloc = 0;
+  std::vector<nbx_ctx*> rank;
+  std::vector<int> dev;
+  std::vector<hipEvent_t> done;      // rank r's NEXT block is complete (copy path)
+  std::vector<Rccl::comm_t> comm;    // RCCL path
+  bool use_rccl = false;
+};
+
+namespace {
+
+int group_exchange(nbx_group* g) {
+  const size_t rec = g->rank[0]->rec;
+  if (g->use_rccl) {
+    // in place: rank r sends its own block, receives every block at its natural offset
+    if (g_rccl.GroupStart() != 0) return fail(NBX_ERR_DEVICE, "ncclGroupStart failed");
+    for (int r = 0; r < g->P; ++r) {
+      nbx_ctx* c = g->rank[r];
+      char* buf = (char*)c->posm[c->cur ^ 1];
+      HIP_TRY(hipSetDevice(g->dev[r]));
+      const int e = g_rccl.AllGather(buf + (size_t)r * g->block * rec, buf, (size_t)g->block * rec, kNcclChar, g->comm[r], c->stream);
+      if (e != 0) {
+        (void)g_rccl.GroupEnd();
+        return fail(NBX_ERR_DEVICE, std::string("ncclAllGather: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "error"));
+      }
+    }
+    if (g_rccl.GroupEnd() != 0) return fail(NBX_ERR_DEVICE, "ncclGroupEnd failed");
+    return NBX_OK;
+  }
+  // copy path: every destination pulls every other rank's block, stream-ordered behind the producer's event
+  for (int r = 0; r < g->P; ++r) {
+    HIP_TRY(hipSetDevice(g->dev[r]));
+    HIP_TRY(hipEventRecord(g->done[r], g->rank[r]->stream));
+  }
+  for (int q = 0; q < g->P; ++q) {
+    nbx_ctx* dst = g->rank[q];
+    HIP_TRY(hipSetDevice(g->dev[q]));
+    for (int r = 0; r < g->P; ++r) {
+      if (r == q) continue;
+      nbx_ctx* src = g->rank[r];
+      const size_t off = (size_t)src->i_begin * rec, bytes = (size_t)src->i_count * rec;
+      HIP_TRY(hipStreamWaitEvent(dst->stream, g->done[r], 0));
+      char* d = (char*)dst->posm[dst->cur ^ 1] + off;
+      const char* s = (const char*)src->posm[src->cur ^ 1] + off;
+      if (g->dev[q] == g->dev[r]) HIP_TRY(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, dst->stream));
+      else HIP_TRY(hipMemcpyPeerAsync(d, g->dev[q], s, g->dev[r], bytes, dst->stream));
+    }
+  }
+  return NBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nbx_group_create(nbx_group** out, int32_t n, int32_t precision, int32_t n_ranks, const int32_t* devices,
+                     const nbx_opts* opts) {
+  if (!out) return fail(NBX_ERR_ARG, "nbx_group_create: out is NULL");
+  *out = nullptr;
+  if (n <= 0) return fail(NBX_ERR_ARG, "nbx_group_create: n must be > 0");
+  if (n_ranks <= 0 || n_ranks > 64) return fail(NBX_ERR_ARG, "nbx_group_create: n_ranks must be in 1..64");
+  if (precision != 32 && precision != 64) return fail(NBX_ERR_ARG, "nbx_group_create: precision must be 32 or 64");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(NBX_ERR_DEVICE, "nbx_group_create: no HIP device available (libnbx has no CPU path)");
+  // balanced, tile-aligned blocks; drop ranks that would own nothing
+  int P = n_ranks, block = 0;
+  for (;; --P) {
+    block = round_up(ceil_div(n, P), kTile);
+    if (P == 1 || (long long)(P - 1) * block < n) break;
+  }
+  nbx_group* g = new (std::nothrow) nbx_group();
+  if (!g) return fail(NBX_ERR_ALLOC, "nbx_group_create: out of host memory");
+  g->n = n; g->precision = precision; g->P = P; g->block = block; g->n_alloc = P * block;
+  bool distinct = true;
+  for (int r = 0; r < P; ++r) {
+    const int d = devices ? devices[r] : r % ndev;
+    if (d < 0 || d >= ndev) { nbx_group_destroy(g); return fail(NBX_ERR_ARG, "nbx_group_create: device ordinal out of range"); }
+    for (int q : g->dev) distinct = distinct && q != d;
+    g->dev.push_back(d);
+  }
+  nbx_opts o;
+  std::memset(&o, 0, sizeof(o));
+  if (opts) {
+    if (opts->struct_size != 0 && opts->struct_size != (int32_t)sizeof(nbx_opts)) {
+      nbx_group_destroy(g);
+      return fail(NBX_ERR_ARG, "nbx_group_create: nbx_opts.struct_size does not match this library");
+    }
+    o = *opts;
+  }
+  o.stream = nullptr; o.external_stream = 0; o.use_graph = 2;  // every rank: own stream, plain launches
+  for (int r = 0; r < P; ++r) {
+    o.device = g->dev[r];
+    o.i_begin = r * block;
+    o.i_count = std::min(n, (r + 1) * block) - r * block;
+    o.n_alloc = g->n_alloc;
+    nbx_ctx* c = nullptr;
+    const int rc = nbx_create(&c, n, precision, &o);
+    if (rc != NBX_OK) { const std::string m = g_err; nbx_group_destroy(g); return fail(rc, "nbx_group_create: rank " + std::to_string(r) + ": " + m); }
+    g->rank.push_back(c);
+  }
+  const char* force = std::getenv("NBX_EXCHANGE");  // "copy" forces the peer-copy path, "rccl" insists on RCCL
+  const bool insist = force && !std::strcmp(force, "rccl");  // also with a single rank: smoke-tests the RCCL binding
+  const bool want_rccl = distinct && (P > 1 || insist) && !(force && !std::strcmp(force, "copy"));
+  if (want_rccl && g_rccl.load()) {
+    g->comm.assign(P, nullptr);
+    const int e = g_rccl.CommInitAll(g->comm.data(), P, g->dev.data());
+    if (e == 0) g->use_rccl = true;
+    else g->comm.clear();
+  }
+  if (insist && !g->use_rccl) {
+    nbx_group_destroy(g);
+    return fail(NBX_ERR_DEVICE, "nbx_group_create: NBX_EXCHANGE=rccl but RCCL is unavailable for these devices");
+  }
+  if (!g->use_rccl) {
+    g->done.assign(P, nullptr);
+    for (int r = 0; r < P; ++r) {
+      if (hipSetDevice(g->dev[r]) != hipSuccess || hipEventCreateWithFlags(&g->done[r], hipEventDisableTiming) != hipSuccess) {
+        nbx_group_destroy(g);
+        return fail(NBX_ERR_DEVICE, "nbx_group_create: hipEventCreate failed");
+      }
+      for (int q = 0; q < P; ++q)  // best effort: direct peer access speeds hipMemcpyPeerAsync up
+        if (g->dev[q] != g->dev[r]) { (void)hipDeviceEnablePeerAccess(g->dev[q], 0); (void)hipGetLastError(); }
+    }
+  }
+  *out = g;
+  g_err.clear();
+  return NBX_OK;
+}
+
+void nbx_group_destroy(nbx_group* g) {
+  if (!g) return;
+  for (nbx_ctx* c : g->rank) if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+  for (auto cm : g->comm) if (cm) (void)g_rccl.CommDestroy(cm);
+  for (size_t r = 0; r < g->done.size(); ++r) if (g->done[r]) { (void)hipSetDevice(g->dev[r]); (void)hipEventDestroy(g->done[r]); }
+  for (nbx_ctx* c : g->rank) nbx_destroy(c);
+  delete g;
+}
+
+int nbx_group_upload(nbx_group* g, const void* px, const void* py, const void* pz, const void* vx, const void* vy,
+                     const void* vz, const void* m) {
+  if (!g) return fail(NBX_ERR_ARG, "nbx_group_upload: group is NULL");
+  for (nbx_ctx* c : g->rank) {
+    const int rc = nbx_upload(c, px, py, pz, vx, vy, vz, m);
+    if (rc) return rc;
+  }
+  return NBX_OK;
+}
+
+int nbx_group_step(nbx_group* g, double dt, int32_t nsteps, double* kenergy_out) {
+  if (!g) return fail(NBX_ERR_ARG, "nbx_group_step: group is NULL");
+  if (nsteps < 0) return fail(NBX_ERR_ARG, "nbx_group_step: nsteps < 0");
+  for (int s = 0; s < nsteps; ++s) {
+    for (nbx_ctx* c : g->rank) {
+      const int rc = nbx_step_local(c, dt);
+      if (rc) return rc;
+    }
+    if (g->P > 1 || g->use_rccl) {
+      const int rc = group_exchange(g);
+      if (rc) return rc;
+    }
+    for (nbx_ctx* c : g->rank) {
+      const int rc = nbx_commit(c);
+      if (rc) return rc;
+    }
+  }
+  if (kenergy_out) {
+    double sum = 0.0;
+    for (nbx_ctx* c : g->rank) {  // rank order: deterministic
+      double part = 0.0;
+      const int rc = nbx_kenergy_partial(c, &part);
+      if (rc) return rc;
+      sum += part;
+    }
+    for (nbx_ctx* c : g->rank) {  // the exchange copies of the last step must have landed too
+      const int rc = nbx_sync(c);
+      if (rc) return rc;
+    }
+    *kenergy_out = 0.5 * sum;
+  }
+  return NBX_OK;
+}
+
+int nbx_group_download(nbx_group* g, void* px, void* py, void* pz, void* vx, void* vy, void* vz) {
+  if (!g) return fail(NBX_ERR_ARG, "nbx_group_download: group is NULL");
+  for (nbx_ctx* c : g->rank) {
+    const int rc = nbx_sync(c);
+    if (rc) return rc;
+  }
+  for (size_t r = 0; r < g->rank.size(); ++r) {  // positions once (rank 0 holds all), velocities per owner
+    const int rc = nbx_download(g->rank[r], r == 0 ? px : nullptr, r == 0 ? py : nullptr, r == 0 ? pz : nullptr, vx, vy, vz);
+    if (rc) return rc;
+  }
+  return NBX_OK;
+}
+
+int nbx_group_info(nbx_group* g, int32_t* n_ranks, int32_t* uses_rccl, int32_t rank, nbx_stats_t* rank_stats) {
+  if (!g) return fail(NBX_ERR_ARG, "nbx_group_info: group is NULL");
+  if (n_ranks) *n_ranks = g->P;
+  if (uses_rccl) *uses_rccl = g->use_rccl ? 1 : 0;
+  if (rank_stats) {
+    if (rank < 0 || rank >= g->P) return fail(NBX_ERR_ARG, "nbx_group_info: rank out of range");
+    return nbx_stats(g->rank[rank], rank_stats);
+  }
+  return NBX_OK;
+}
+
+}  // extern "C"
+

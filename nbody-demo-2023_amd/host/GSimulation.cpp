@@ -158,11 +158,22 @@ void GSimulation::start() {
   if (kv && !std::strcmp(kv, "lds")) opts.kernel_variant = NBX_KERNEL_LDS;
   if (kv && !std::strcmp(kv, "sgprw")) opts.kernel_variant = NBX_KERNEL_SGPRW;
 
+  // NBODY_GPUS=k: block-partition the bodies over k GPUs of this node (one all-gather of positions per step);
+  // k larger than the device count gives logical ranks sharing devices.  Default: one context on one GPU.
+  const int gpus = env_int("NBODY_GPUS", 1);
   nbx_ctx* ctx = NULL;
-  if (nbx_create(&ctx, n, kPrecisionBits, &opts)) die_nbx("nbx_create");
-  if (nbx_upload(ctx, particles->pos_x, particles->pos_y, particles->pos_z, particles->vel_x, particles->vel_y,
-                 particles->vel_z, particles->mass))
-    die_nbx("nbx_upload");
+  nbx_group* grp = NULL;
+  if (gpus > 1 || std::getenv("NBX_EXCHANGE")) {
+    if (nbx_group_create(&grp, n, kPrecisionBits, gpus, NULL, &opts)) die_nbx("nbx_group_create");
+    if (nbx_group_upload(grp, particles->pos_x, particles->pos_y, particles->pos_z, particles->vel_x, particles->vel_y,
+                         particles->vel_z, particles->mass))
+      die_nbx("nbx_group_upload");
+  } else {
+    if (nbx_create(&ctx, n, kPrecisionBits, &opts)) die_nbx("nbx_create");
+    if (nbx_upload(ctx, particles->pos_x, particles->pos_y, particles->pos_z, particles->vel_x, particles->vel_y,
+                   particles->vel_z, particles->mass))
+      die_nbx("nbx_upload");
+  }
 
   _totTime = 0.;
   const double nd = double(n);
@@ -178,8 +189,13 @@ void GSimulation::start() {
     const bool printed = (todo == sfreq);
     double ke = 0.0;
     const double w0 = time.start();
-    if (nbx_step(ctx, dt, todo, printed ? &ke : NULL)) die_nbx("nbx_step");
-    if (!printed && nbx_sync(ctx)) die_nbx("nbx_sync");
+    if (grp) {
+      double tail_ke = 0.0;  // asking for the energy is what synchronises a group
+      if (nbx_group_step(grp, dt, todo, printed ? &ke : &tail_ke)) die_nbx("nbx_group_step");
+    } else {
+      if (nbx_step(ctx, dt, todo, printed ? &ke : NULL)) die_nbx("nbx_step");
+      if (!printed && nbx_sync(ctx)) die_nbx("nbx_sync");
+    }
     const double w1 = time.stop();
     done += todo;
     if (!printed) break;
@@ -203,14 +219,22 @@ void GSimulation::start() {
   dev = std::sqrt(dev / (double)(nf - 2) - av * av);
 
   nbx_stats_t st;
-  if (nbx_stats(ctx, &st)) die_nbx("nbx_stats");
-
+  int32_t ranks = 1, rccl = 0;
   // leave particles->* as the reference does after its last step (acc zeroed by the update loop)
-  if (nbx_download(ctx, particles->pos_x, particles->pos_y, particles->pos_z, particles->vel_x, particles->vel_y,
-                   particles->vel_z))
-    die_nbx("nbx_download");
+  if (grp) {
+    if (nbx_group_info(grp, &ranks, &rccl, 0, &st)) die_nbx("nbx_group_info");
+    if (nbx_group_download(grp, particles->pos_x, particles->pos_y, particles->pos_z, particles->vel_x, particles->vel_y,
+                           particles->vel_z))
+      die_nbx("nbx_group_download");
+    nbx_group_destroy(grp);
+  } else {
+    if (nbx_stats(ctx, &st)) die_nbx("nbx_stats");
+    if (nbx_download(ctx, particles->pos_x, particles->pos_y, particles->pos_z, particles->vel_x, particles->vel_y,
+                     particles->vel_z))
+      die_nbx("nbx_download");
+    nbx_destroy(ctx);
+  }
   init_acc();
-  nbx_destroy(ctx);
   // NBODY_SNAPSHOT=<file>: keep the final state (the reference drops it at exit)
   if (const char* sp = std::getenv("NBODY_SNAPSHOT")) {
     std::string err;
@@ -230,6 +254,9 @@ void GSimulation::start() {
             << ", kernel " << (st.kernel_variant == NBX_KERNEL_LDS ? "lds" : st.kernel_variant == NBX_KERNEL_SGPR ? "sgpr" : "sgprw")
             << ", bodies/lane " << st.bodies_per_lane << ", j-split " << st.j_split << ", grid " << st.force_grid_x << "x"
             << st.force_grid_y << std::endl;
+  if (ranks > 1)
+    std::cout << "# GPUs / ranks       : " << ranks << " x " << st.i_count << " bodies, position all-gather per step over "
+              << (rccl ? "RCCL" : "device-to-device copies") << std::endl;
   if (nf > 2) {
     const double pairs_per_s = av / 29.0 * 1e9;  // GFlops(29/pair) -> pair/s, integration term ignored
     std::cout << "# Pair rate          : " << pairs_per_s * 1e-9 << " G pair/s = "

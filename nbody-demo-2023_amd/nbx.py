@@ -21,7 +21,8 @@ SYMBOLS = (
     "nbx_last_error", "nbx_abi_version", "nbx_create", "nbx_destroy", "nbx_upload", "nbx_step",
     "nbx_step_trace", "nbx_step_local", "nbx_exchange_buffer", "nbx_commit", "nbx_kenergy_partial",
     "nbx_accel", "nbx_sync", "nbx_download", "nbx_ic_pos", "nbx_ic_vel", "nbx_ic_mass", "nbx_profile",
-    "nbx_stats",
+    "nbx_stats", "nbx_group_create", "nbx_group_destroy", "nbx_group_upload", "nbx_group_step", "nbx_group_download",
+    "nbx_group_info",
 )
 
 
@@ -101,6 +102,13 @@ def load():
     L.nbx_ic_mass.argtypes = [i32, i32, vp]
     L.nbx_profile.argtypes = [vp, i32]
     L.nbx_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+    L.nbx_group_create.argtypes = [ctypes.POINTER(vp), i32, i32, i32, ctypes.POINTER(i32), ctypes.POINTER(Opts)]
+    L.nbx_group_destroy.argtypes = [vp]
+    L.nbx_group_destroy.restype = None
+    L.nbx_group_upload.argtypes = [vp] + [vp] * 7
+    L.nbx_group_step.argtypes = [vp, dbl, i32, ctypes.POINTER(dbl)]
+    L.nbx_group_download.argtypes = [vp] + [vp] * 6
+    L.nbx_group_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), i32, ctypes.POINTER(Stats)]
     _lib = L
     return L
 
@@ -231,6 +239,52 @@ class Context:
         s = Stats()
         _check(self._L.nbx_stats(self._h, ctypes.byref(s)), "nbx_stats")
         return s.asdict()
+
+
+class Group:
+    """One nbx_group: n_ranks contexts driven by this process (multi-GPU; logical ranks when devices repeat)."""
+
+    def __init__(self, n, precision=32, n_ranks=1, devices=None, **opts):
+        self._L = load()
+        self._h = ctypes.c_void_p()
+        self.n, self.precision, self.dtype = int(n), int(precision), _dtype(precision)
+        o = Opts()
+        o.struct_size = ctypes.sizeof(Opts)
+        for k, v in opts.items():
+            setattr(o, k, v)
+        dev = None if devices is None else (ctypes.c_int32 * len(devices))(*devices)
+        _check(self._L.nbx_group_create(ctypes.byref(self._h), self.n, self.precision, n_ranks, dev, ctypes.byref(o)),
+               "nbx_group_create")
+
+    def close(self):
+        if self._h:
+            self._L.nbx_group_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def upload(self, state):
+        arrs = [np.ascontiguousarray(state[f], dtype=self.dtype) for f in FIELDS]
+        _check(self._L.nbx_group_upload(self._h, *[_ptr(a) for a in arrs]), "nbx_group_upload")
+
+    def step(self, nsteps, dt=DT, kenergy=True):
+        ke = ctypes.c_double(0.0)
+        _check(self._L.nbx_group_step(self._h, dt, nsteps, ctypes.byref(ke) if kenergy else None), "nbx_group_step")
+        return ke.value if kenergy else None
+
+    def download(self):
+        out = {f: np.zeros(self.n, dtype=self.dtype) for f in FIELDS[:6]}
+        _check(self._L.nbx_group_download(self._h, *[_ptr(out[f]) for f in FIELDS[:6]]), "nbx_group_download")
+        return out
+
+    def info(self, rank=0):
+        P, rccl, st = ctypes.c_int32(), ctypes.c_int32(), Stats()
+        _check(self._L.nbx_group_info(self._h, ctypes.byref(P), ctypes.byref(rccl), rank, ctypes.byref(st)), "nbx_group_info")
+        return P.value, bool(rccl.value), st.asdict()
 
 
 def read_snapshot(path):

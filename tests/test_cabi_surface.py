@@ -62,6 +62,13 @@ def test_create_rejects_bad_slice_and_null(nbx):
     assert L.nbx_step(None, 0.1, 1, None) == nbx.NBX_ERR_ARG
     assert L.nbx_stats(None, None) == nbx.NBX_ERR_ARG
     L.nbx_destroy(None)  # NULL-safe
+    L.nbx_group_destroy(None)
+    assert L.nbx_group_create(None, 10, 32, 2, None, None) == nbx.NBX_ERR_ARG
+    assert L.nbx_group_step(None, 0.1, 1, None) == nbx.NBX_ERR_ARG
+    for args in ((0, 32, 2), (100, 32, 0), (100, 32, 65), (100, 8, 2)):
+        with pytest.raises(nbx.NbxError) as e:
+            nbx.Group(args[0], args[1], n_ranks=args[2])
+        assert e.value.code == nbx.NBX_ERR_ARG, args
     assert b"ctx is NULL" in L.nbx_last_error() or L.nbx_last_error() != b""
 
 

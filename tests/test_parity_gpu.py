@@ -517,3 +517,68 @@ def test_cli_snapshot_and_restart(nbx, tmp_path):
         assert np.array_equal(d[f], sc[f]), f
     bad = run(["2999", "10"], {"NBODY_RESTART": a})
     assert bad.returncode == 1 and "snapshot holds 3000 bodies" in bad.stderr
+
+
+# ---- nbx_group: the single-process multi-GPU driver behind `NBODY_GPUS=k ./nbody.x` --------------------
+@pytest.mark.parametrize("n,P", [(2000, 2), (4099, 4), (16384, 8), (300, 8)])
+def test_group_of_logical_ranks_bit_equal_to_single_context(nbx, n, P):
+    """All ranks on device 0 (the only one here): the same partition / step_local / exchange / commit sequence
+    the multi-GPU run performs, with the exchange as stream-ordered device-to-device copies."""
+    import sharded
+    ic = nbx.initial_conditions(n)
+    steps = 15
+    with nbx.Group(n, 32, n_ranks=P, devices=[0] * P, j_split=4, bodies_per_lane=2) as g:
+        Peff, rccl, st0 = g.info(0)
+        assert not rccl and 1 <= Peff <= P
+        g.upload(ic)
+        ke_g = [g.step(5), g.step(5), g.step(5)]
+        dg = g.download()
+        st0 = g.info(0)[2]
+        stl = g.info(Peff - 1)[2]
+    assert st0["i_begin"] == 0 and stl["i_begin"] + stl["i_count"] == n and st0["steps_done"] == steps
+    if n == 300:
+        assert Peff == 2            # 256-record blocks: ranks that would own nothing are dropped
+    n_alloc = st0["n_alloc"]
+    assert n_alloc == sharded.block_partition(n, Peff, 0)[3]
+    with nbx.Context(n, j_split=4, bodies_per_lane=2, n_alloc=n_alloc) as c:
+        c.upload(ic)
+        ke_c = [c.step(5), c.step(5), c.step(5)]
+        dc = c.download()
+    for f in dc:
+        assert np.array_equal(dg[f], dc[f]), f
+    assert rel_err(ke_g, ke_c).max() < 1e-12
+
+
+def test_cli_multi_gpu_env(nbx):
+    import subprocess
+    exe = os.path.join(ROOT, "nbody-demo-2023_amd", "host", "nbody.x")
+    one = subprocess.run([exe, "4099", "100"], capture_output=True, text=True, timeout=300)
+    four = subprocess.run([exe, "4099", "100"], env=dict(os.environ, NBODY_GPUS="4"), capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0 and four.returncode == 0, four.stderr
+    r1, r4 = _rows(one.stdout.splitlines()), _rows(four.stdout.splitlines())
+    assert [r[2] for r in r1] == [r[2] for r in r4] and len(r4) == 2
+    assert any(ln.startswith("# GPUs / ranks       : 4 x ") for ln in four.stdout.splitlines())
+
+
+def test_group_rccl_binding_with_one_rank(nbx):
+    """NBX_EXCHANGE=rccl with a single rank: librccl is dlopen'ed, ncclCommInitAll / grouped in-place ncclAllGather run
+    on the context's stream (the multi-device form of this call cannot run on a 1-GPU box).  Through the CLI too, where
+    the system RCCL -- not the copy PyTorch bundles -- is the one that gets loaded."""
+    import subprocess
+    exe = os.path.join(ROOT, "nbody-demo-2023_amd", "host", "nbody.x")
+    ref = subprocess.run([exe, "3000", "100"], capture_output=True, text=True, timeout=300)
+    got = subprocess.run([exe, "3000", "100"], env=dict(os.environ, NBX_EXCHANGE="rccl", NBODY_GPUS="1"), capture_output=True, text=True, timeout=300)
+    assert got.returncode == 0, got.stderr[-2000:]
+    assert [r[2] for r in _rows(got.stdout.splitlines())] == [r[2] for r in _rows(ref.stdout.splitlines())]
+    os.environ["NBX_EXCHANGE"] = "rccl"
+    try:
+        with nbx.Group(3000, 32, n_ranks=1, devices=[0]) as g:
+            P, rccl, _ = g.info(0)
+            assert P == 1 and rccl
+            g.upload(nbx.initial_conditions(3000))
+            ke = g.step(20)
+    finally:
+        del os.environ["NBX_EXCHANGE"]
+    with nbx.Context(3000, use_graph=2) as c:
+        c.upload(nbx.initial_conditions(3000))
+        assert c.step(20) == ke
