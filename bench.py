@@ -201,6 +201,20 @@ def main():
     st = sim.engine.ctx.stats()
     ke = sim.kenergy()
 
+    # N == 1 only: the multi-GPU runs use configs[3]'s n = 1048576; time a few steps of it on this one GPU as
+    # well, so that scaling can also be read at equal n (pair/s is nearly flat in n here, see profiles/r01_sweep_*)
+    same_n = None
+    if world == 1 and not a.n and a.precision == 32:
+        big = sharded.ShardedSimulation(1048576, 32, dist=None, **opts)
+        big.upload(nbx.initial_conditions(1048576, 32))
+        big.step(1)
+        big.sync()
+        tb = time.perf_counter()
+        big.step(3)
+        big.sync()
+        same_n = {"n_bodies": 1048576, "steps": 3, "value": 3.0 * 1048576.0 ** 2 / (time.perf_counter() - tb), "unit": "pair/s"}
+        big.close()
+
     if rank == 0:
         pairs_per_step = float(n) * float(n)
         value = pairs_per_step * a.steps / elapsed
@@ -238,6 +252,8 @@ def main():
         }
         if parity:
             line["parity"] = parity
+        if same_n:
+            line["one_gpu_at_multi_gpu_n"] = same_n
         if cpu:
             line["cpu_baseline"] = cpu
             line["gpu_over_cpu"] = value / cpu["value"]

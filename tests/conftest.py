@@ -42,6 +42,15 @@ def nbx():
     return N
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_tree():
+    """A fresh checkout has no binaries (they are git-ignored): build what the tests execute."""
+    host = os.path.join(PKG, "host")
+    if not all(os.path.exists(os.path.join(host, x)) for x in ("nbody.x", "nbody_fp64.x", "nbody_v5.x")) \
+            or not os.path.exists(os.path.join(PKG, "libnbx.so")):
+        subprocess.check_call(["make", "-s", "-C", ROOT, "lib", "host"])
+
+
 def load_golden(name):
     with open(os.path.join(GOLD, name)) as f:
         return json.load(f)

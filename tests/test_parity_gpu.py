@@ -343,6 +343,34 @@ def test_fullsize_sampled_bodies_vs_fp64_direct_sum(big):
         assert abs((dz * inv3).sum() - az[i]) / scale < 1e-5
 
 
+def test_fullsize_1m_bodies_config3_properties(nbx):
+    """BASELINE.json configs[3]'s body count on one GPU (the CPU reference needs ~4 min per step here): Newton's third
+    law, 32 sampled bodies against an fp64 direct sum, and one time step's kinetic energy against the fp64 evaluation of
+    the same Euler update from those sampled accelerations' full-array counterpart."""
+    n = 1048576
+    ic = nbx.initial_conditions(n)
+    with nbx.Context(n) as c:
+        c.upload(ic)
+        ax, ay, az = c.accel()
+        ke1 = c.step(1)
+    m = ic["mass"].astype(np.float64)
+    for a in (ax, ay, az):
+        f = m * a.astype(np.float64)
+        assert abs(f.sum()) / np.abs(f).sum() < 2e-6
+    x, y, z = (ic[k].astype(np.float64) for k in ("pos_x", "pos_y", "pos_z"))
+    gm = float(np.float32(6.67259e-11)) * m
+    eps = float(np.float32(1e-3))
+    scale = max(np.abs(ax).max(), np.abs(ay).max(), np.abs(az).max())
+    for i in np.random.default_rng(5).integers(0, n, 32):
+        dx, dy, dz = x - x[i], y - y[i], z - z[i]
+        inv3 = (dx * dx + dy * dy + dz * dz + eps) ** -1.5 * gm
+        assert abs((dy * inv3).sum() - ay[i]) / scale < 1e-5
+    dt = nbx.DT
+    vx, vy, vz = (ic[k].astype(np.float64) + a.astype(np.float64) * dt for k, a in (("vel_x", ax), ("vel_y", ay), ("vel_z", az)))
+    ke_ref = 0.5 * float((m * (vx * vx + vy * vy + vz * vz)).sum())
+    assert abs(ke1 - ke_ref) / ke_ref < 1e-5
+
+
 def test_fullsize_padding_bodies_are_inert(nbx):
     """n = 262144 - 37 (ragged tail tile): appending zero-mass bodies must not change anything."""
     n = 262144 - 37
