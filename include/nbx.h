@@ -64,8 +64,10 @@ typedef struct nbx_opts {
   int32_t bodies_per_lane; /* register blocking of i-bodies: 1,2,4,8; 0 = auto */
   int32_t j_split;         /* workgroups sharing one i-block, each summing a j-range; 0 = auto */
   int32_t kernel_variant;  /* NBX_KERNEL_* */
-  int32_t fused_epilogue;  /* 0 = auto (fused when j_split == 1), 1 = on where possible, 2 = off
-                              (always the separate integrate kernel) */
+  int32_t fused_epilogue;  /* 0 = auto (integrate inside the force kernel only when j_split == 1), 1 = always one
+                              launch per step (with j-splits the last workgroup to arrive at an i-block integrates
+                              it; measured slower than the extra launch on MI355X), 2 = always the separate
+                              integrate kernel */
   int32_t use_graph;       /* 0 = auto, 1 = replay multi-step windows from a hipGraph, 2 = plain launches */
   int32_t external_stream; /* 0 = own non-blocking stream; 1 = enqueue everything on `stream` (caller-owned) */
   int32_t reserved[4];
@@ -73,7 +75,8 @@ typedef struct nbx_opts {
 
 typedef struct nbx_stats_t {
   int32_t n, n_alloc, i_begin, i_count, precision;
-  int32_t bodies_per_lane, j_split, j_tile, kernel_variant, fused_epilogue;
+  int32_t bodies_per_lane, j_split, j_tile, kernel_variant;
+  int32_t fused_epilogue;      /* 0 separate integrate kernel, 1 integrated directly (one split), 2 last-arriver */
   int32_t force_grid_x, force_grid_y, force_block;
   int32_t cu_count, clock_mhz;
   int64_t steps_done;          /* time steps executed since create */

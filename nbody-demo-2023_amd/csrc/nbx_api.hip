@@ -43,7 +43,7 @@ constexpr int kMaxProfiledLaunches = 8192;
 
 struct nbx_ctx {
   int n = 0, n_alloc = 0, i_begin = 0, i_count = 0, own_pad = 0, precision = 32;
-  int B = 1, S = 1, jps = 0, variant = NBX_KERNEL_LDS, fused = 0, math = MATH_SCALAR;
+  int B = 1, S = 1, jps = 0, variant = NBX_KERNEL_LDS, epi = EPI_SLAB, math = MATH_SCALAR;
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -53,6 +53,7 @@ struct nbx_ctx {
   void* velm = nullptr;
   void* accp = nullptr;
   double* ke_part = nullptr;
+  unsigned int* arrive = nullptr;  // EPI_LAST arrival counters, one per i-block
   int ke_parts = 0;       // partials written by the last step
   double* ke_dev = nullptr;  // [ke_cap] reduced sums (sum m v^2)
   int ke_cap = 0;
@@ -79,43 +80,52 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // kernel dispatch
 // ------------------------------------------------------------------------------------------
-template <typename T, int B, int JSRC, bool FUSED, int MATH, bool WS>
+template <typename T, int B, int JSRC, int EPI, int MATH, bool WS>
 void launch_force_t(const ForceArgs<T>& a, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((force_kernel<T, B, JSRC, FUSED, 1, MATH, WS>), grid, dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((force_kernel<T, B, JSRC, EPI, 1, MATH, WS>), grid, dim3(kBlock), 0, st, a);
 }
 
 template <typename T>
 using ForceLauncher = void (*)(const ForceArgs<T>&, dim3, hipStream_t);
 
-template <typename T, int JSRC, bool FUSED, int MATH, bool WS>
+template <typename T, int JSRC, int EPI, int MATH, bool WS>
 ForceLauncher<T> pick_b(int B) {
   switch (B) {
     case 1:
-      if constexpr (MATH == MATH_SCALAR) return launch_force_t<T, 1, JSRC, FUSED, MATH, WS>;
+      if constexpr (MATH == MATH_SCALAR) return launch_force_t<T, 1, JSRC, EPI, MATH, WS>;
       return nullptr;
-    case 2: return launch_force_t<T, 2, JSRC, FUSED, MATH, WS>;
-    case 4: return launch_force_t<T, 4, JSRC, FUSED, MATH, WS>;
+    case 2: return launch_force_t<T, 2, JSRC, EPI, MATH, WS>;
+    case 4: return launch_force_t<T, 4, JSRC, EPI, MATH, WS>;
     case 8:
-      if constexpr (sizeof(T) == 4 && !WS) return launch_force_t<T, 8, JSRC, FUSED, MATH, WS>;
+      if constexpr (sizeof(T) == 4 && !WS) return launch_force_t<T, 8, JSRC, EPI, MATH, WS>;
       return nullptr;
   }
   return nullptr;
 }
 
+template <typename T, int JSRC, int MATH, bool WS>
+ForceLauncher<T> pick_epi(int B, int epi) {
+  if (epi == EPI_LAST) return pick_b<T, JSRC, EPI_LAST, MATH, WS>(B);
+  if (epi == EPI_ROW) {
+    if constexpr (!WS) return pick_b<T, JSRC, EPI_ROW, MATH, WS>(B);
+    return nullptr;
+  }
+  return pick_b<T, JSRC, EPI_SLAB, MATH, WS>(B);
+}
+
 template <typename T, int MATH>
-ForceLauncher<T> pick(int B, int variant, bool fused) {
-  if (variant == NBX_KERNEL_SGPRW) return fused ? nullptr : pick_b<T, JSRC_SGPR, false, MATH, true>(B);
-  if (variant == NBX_KERNEL_SGPR)
-    return fused ? pick_b<T, JSRC_SGPR, true, MATH, false>(B) : pick_b<T, JSRC_SGPR, false, MATH, false>(B);
-  return fused ? pick_b<T, JSRC_LDS, true, MATH, false>(B) : pick_b<T, JSRC_LDS, false, MATH, false>(B);
+ForceLauncher<T> pick(int B, int variant, int epi) {
+  if (variant == NBX_KERNEL_SGPRW) return pick_epi<T, JSRC_SGPR, MATH, true>(B, epi);
+  if (variant == NBX_KERNEL_SGPR) return pick_epi<T, JSRC_SGPR, MATH, false>(B, epi);
+  return pick_epi<T, JSRC_LDS, MATH, false>(B, epi);
 }
 
 template <typename T>
-ForceLauncher<T> pick_force(const nbx_ctx* c, bool fused) {
+ForceLauncher<T> pick_force(const nbx_ctx* c, int epi) {
   if constexpr (sizeof(T) == 4) {
-    if (c->math == MATH_PACKED) return pick<float, MATH_PACKED>(c->B, c->variant, fused);
+    if (c->math == MATH_PACKED) return pick<float, MATH_PACKED>(c->B, c->variant, epi);
   }
-  return pick<T, MATH_SCALAR>(c->B, c->variant, fused);
+  return pick<T, MATH_SCALAR>(c->B, c->variant, epi);
 }
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -132,7 +142,6 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   const int target_wgs = cus * 32;
   int variant = o.kernel_variant;
   if (variant != NBX_KERNEL_LDS && variant != NBX_KERNEL_SGPR && variant != NBX_KERNEL_SGPRW) variant = NBX_KERNEL_SGPRW;
-  if (o.fused_epilogue == 1 && variant == NBX_KERNEL_SGPRW && o.j_split == 1) variant = NBX_KERNEL_SGPR;
   const int maxB = (c->precision == 32 && variant != NBX_KERNEL_SGPRW) ? 8 : 4;
   int B = o.bodies_per_lane;
   if (B != 1 && B != 2 && B != 4 && B != 8) B = 0;
@@ -157,14 +166,19 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   c->jps = jps;
   c->math = (c->precision == 32 && B >= 2) ? MATH_PACKED : MATH_SCALAR;
   c->variant = variant;
-  // fused_epilogue: 0 auto, 1 on, 2 off; only without a j-split and not for the wave-split kernel
-  c->fused = (S == 1 && o.fused_epilogue != 2 && variant != NBX_KERNEL_SGPRW) ? 1 : 0;
+  // fused_epilogue: 0 auto, 1 on, 2 off.  A single split integrates directly (EPI_ROW).  With splits, "on" lets the
+  // last workgroup to arrive at an i-block integrate it (EPI_LAST: one launch per step) -- measured SLOWER than the
+  // separate integrate kernel on MI355X (n=2048: 18 us vs 7 + 5 us; n=16384: 77 vs 66 + 5 us: every workgroup pays an
+  // agent-scope release, ~2-6 us, where a kernel boundary costs ~1.5 us), so auto never picks it.
+  if (o.fused_epilogue == 2) c->epi = EPI_SLAB;
+  else if (S == 1 && variant != NBX_KERNEL_SGPRW) c->epi = EPI_ROW;
+  else c->epi = (o.fused_epilogue == 1) ? EPI_LAST : EPI_SLAB;
   c->grid = dim3(ceil_div(c->i_count, iblk), S);
 }
 
 template <typename T>
-int enqueue_force(nbx_ctx* c, bool fused, double dt) {
-  ForceLauncher<T> fn = pick_force<T>(c, fused);
+int enqueue_force(nbx_ctx* c, int epi, double dt) {
+  ForceLauncher<T> fn = pick_force<T>(c, epi);
   if (!fn) return fail(NBX_ERR_ARG, "no kernel instance for this bodies_per_lane / precision");
   ForceArgs<T> a{};
   using T4 = typename V4<T>::type;
@@ -173,6 +187,7 @@ int enqueue_force(nbx_ctx* c, bool fused, double dt) {
   a.velm = (T4*)c->velm;
   a.posm_next = (T4*)c->posm[c->cur ^ 1];
   a.ke_part = c->ke_part;
+  a.arrive = c->arrive;
   a.i_begin = c->i_begin;
   a.i_count = c->i_count;
   a.own_pad = c->own_pad;
@@ -194,9 +209,9 @@ int enqueue_force(nbx_ctx* c, bool fused, double dt) {
 template <typename T>
 int enqueue_step(nbx_ctx* c, double dt) {
   using T4 = typename V4<T>::type;
-  int rc = enqueue_force<T>(c, c->fused != 0, dt);
+  int rc = enqueue_force<T>(c, c->epi, dt);
   if (rc) return rc;
-  if (c->fused) {
+  if (c->epi != EPI_SLAB) {
     c->ke_parts = c->grid.x;
   } else {
     const int blocks = ceil_div(c->i_count, kBlock);
@@ -327,7 +342,7 @@ int download_t(nbx_ctx* c, T* px, T* py, T* pz, T* vx, T* vy, T* vz) {
 template <typename T>
 int accel_t(nbx_ctx* c, T* ax, T* ay, T* az) {
   using T4 = typename V4<T>::type;
-  int rc = enqueue_force<T>(c, false, 0.0);
+  int rc = enqueue_force<T>(c, EPI_SLAB, 0.0);
   if (rc) return rc;
   std::vector<T4> h((size_t)c->S * c->own_pad);
   HIP_TRY(hipMemcpyAsync(h.data(), c->accp, sizeof(T4) * h.size(), hipMemcpyDeviceToHost, c->stream));
@@ -425,6 +440,8 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
   CREATE_TRY(hipMalloc(&c->accp, c->rec * (size_t)c->own_pad * c->S));
   const int max_parts = std::max(ceil_div(c->i_count, kBlock), (int)c->grid.x);
   CREATE_TRY(hipMalloc(&c->ke_part, sizeof(double) * (size_t)max_parts));
+  CREATE_TRY(hipMalloc(&c->arrive, sizeof(unsigned int) * (size_t)max_parts));
+  CREATE_TRY(hipMemsetAsync(c->arrive, 0, sizeof(unsigned int) * (size_t)max_parts, c->stream));
   CREATE_TRY(hipMemsetAsync(c->posm[0], 0, pos_bytes, c->stream));
   CREATE_TRY(hipMemsetAsync(c->posm[1], 0, pos_bytes, c->stream));
   CREATE_TRY(hipMemsetAsync(c->ke_part, 0, sizeof(double) * (size_t)max_parts, c->stream));
@@ -451,6 +468,7 @@ void nbx_destroy(nbx_ctx* c) {
   if (c->velm) (void)hipFree(c->velm);
   if (c->accp) (void)hipFree(c->accp);
   if (c->ke_part) (void)hipFree(c->ke_part);
+  if (c->arrive) (void)hipFree(c->arrive);
   if (c->ke_dev) (void)hipFree(c->ke_dev);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -468,6 +486,8 @@ int nbx_upload(nbx_ctx* c, const void* px, const void* py, const void* pz, const
            : upload_t<double>(c, (const double*)px, (const double*)py, (const double*)pz, (const double*)vx,
                               (const double*)vy, (const double*)vz, (const double*)m);
   if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(c->arrive, 0, sizeof(unsigned int) * (size_t)std::max(ceil_div(c->i_count, kBlock), (int)c->grid.x), c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   c->cur = 0;
   c->uploaded = true;
   c->pending_commit = false;
@@ -656,7 +676,7 @@ int nbx_stats(nbx_ctx* c, nbx_stats_t* s) {
   std::memset(s, 0, sizeof(*s));
   s->n = c->n; s->n_alloc = c->n_alloc; s->i_begin = c->i_begin; s->i_count = c->i_count;
   s->precision = c->precision; s->bodies_per_lane = c->B; s->j_split = c->S; s->j_tile = kTile;
-  s->kernel_variant = c->variant; s->fused_epilogue = c->fused;
+  s->kernel_variant = c->variant; s->fused_epilogue = c->epi;
   s->force_grid_x = c->grid.x; s->force_grid_y = c->grid.y; s->force_block = kBlock;
   s->cu_count = c->prop.multiProcessorCount; s->clock_mhz = c->prop.clockRate / 1000;
   s->steps_done = c->steps_done;

@@ -131,10 +131,11 @@ __device__ __forceinline__ T euler_update(T ax, T ay, T az, T dt, typename V4<T>
 template <typename T>
 struct ForceArgs {
   const typename V4<T>::type* posm;  // current positions, n_alloc records
-  typename V4<T>::type* accp;        // [gridDim.y][own_pad], written when !FUSED
-  typename V4<T>::type* velm;        // FUSED: owned velocities, updated in place
-  typename V4<T>::type* posm_next;   // FUSED: next position buffer (owned slice written)
-  double* ke_part;                   // FUSED: one partial per workgroup
+  typename V4<T>::type* accp;        // [gridDim.y][own_pad] partial-acceleration slabs (EPI_SLAB, EPI_LAST)
+  typename V4<T>::type* velm;        // EPI_ROW / EPI_LAST: owned velocities, updated in place
+  typename V4<T>::type* posm_next;   // EPI_ROW / EPI_LAST: next position buffer (owned slice written)
+  double* ke_part;                   // EPI_ROW / EPI_LAST: one partial per i-block (blockIdx.x)
+  unsigned int* arrive;              // EPI_LAST: one arrival counter per i-block, zero between launches
   int i_begin, i_count, own_pad;
   int j_per_split;                   // split y covers [y*jps, min((y+1)*jps, n_alloc)); multiple of kTile for the
                                      // LDS source, of 2*kSgprBatch (x4 under WSPLIT) for the SGPR source
@@ -179,6 +180,13 @@ template <> struct SgprBatch<double> {
   __device__ __forceinline__ double w(int u) const { return r[4 * u + 3]; }
 };
 enum : int { MATH_SCALAR = 0, MATH_PACKED = 1 };
+// What a workgroup does with its accelerations:
+//   EPI_SLAB  write them to its split's slab (the separate integrate_kernel, or nbx_accel, consumes the slabs)
+//   EPI_ROW   single split (gridDim.y == 1): integrate its bodies directly, no slab
+//   EPI_LAST  write the slab, then the LAST workgroup of the i-block to arrive (agent-scope release / counter /
+//             acquire, guide section 6 G16) sums the slabs in split order and integrates: one launch per time step
+//             with exactly the arithmetic of integrate_kernel, hence the same bits
+enum : int { EPI_SLAB = 0, EPI_ROW = 1, EPI_LAST = 2 };
 
 // The B i-bodies a lane keeps in registers, and how one j record is applied to them.
 template <typename T, int B, int MATH>
@@ -221,10 +229,10 @@ struct IBodies<float, B, MATH_PACKED> {
 //     j range; the four partial sums are added in wave order through LDS.  Four times the workgroups
 //     for the same number of partial-acceleration slabs.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int B, int JSRC, bool FUSED, int MINW, int MATH = MATH_SCALAR, bool WSPLIT = false>
+template <typename T, int B, int JSRC, int EPI, int MINW, int MATH = MATH_SCALAR, bool WSPLIT = false>
 __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> a) {
   using T4 = typename V4<T>::type;
-  static_assert(!WSPLIT || (JSRC == JSRC_SGPR && !FUSED), "wave split exists for the unfused SGPR kernel only");
+  static_assert(!WSPLIT || (JSRC == JSRC_SGPR && EPI != EPI_ROW), "wave split exists for the SGPR kernel with slabs only");
   const int t = threadIdx.x;
   constexpr int kStride = WSPLIT ? 64 : kBlock;  // distance between a lane's consecutive bodies
   const int base = blockIdx.x * (kStride * B) + (WSPLIT ? (t & 63) : t);
@@ -307,44 +315,7 @@ __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> 
     }
   }
 
-  if constexpr (WSPLIT) {
-    __shared__ T red[3][3][B][64];  // [wave-1][component][body][lane]
-    const int lane = t & 63, wave = t >> 6;
-    if (wave > 0) {
-#pragma unroll
-      for (int b = 0; b < B; ++b) {
-        T x, y, z;
-        ib.get(b, x, y, z);
-        red[wave - 1][0][b][lane] = x; red[wave - 1][1][b][lane] = y; red[wave - 1][2][b][lane] = z;
-      }
-    }
-    __syncthreads();
-    if (wave == 0) {
-      T4* out = a.accp + (size_t)blockIdx.y * a.own_pad;
-#pragma unroll
-      for (int b = 0; b < B; ++b) {
-        const int li = base + b * kStride;
-        T4 r;
-        ib.get(b, r.x, r.y, r.z);
-#pragma unroll
-        for (int w = 0; w < 3; ++w) { r.x += red[w][0][b][lane]; r.y += red[w][1][b][lane]; r.z += red[w][2][b][lane]; }
-        r.w = (T)0;
-        if (li < a.i_count) out[li] = r;
-      }
-    }
-  } else if constexpr (!FUSED) {
-    T4* out = a.accp + (size_t)blockIdx.y * a.own_pad;
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-      const int li = base + b * kBlock;
-      if (li < a.i_count) {
-        T4 r;
-        ib.get(b, r.x, r.y, r.z);
-        r.w = (T)0;
-        out[li] = r;
-      }
-    }
-  } else {
+  if constexpr (EPI == EPI_ROW) {
     __shared__ double ksum[4];
     double ke = 0.0;
 #pragma unroll
@@ -362,6 +333,95 @@ __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> 
     }
     const double s = block_sum(ke, ksum);
     if (t == 0) a.ke_part[blockIdx.x] = s;
+    return;
+  }
+
+  // ---- this workgroup's partial accelerations -> slab blockIdx.y -------------------------------
+  T4* out = a.accp + (size_t)blockIdx.y * a.own_pad;
+  if constexpr (WSPLIT) {
+    __shared__ T red[3][3][B][64];  // [wave-1][component][body][lane]
+    const int lane = t & 63, wave = t >> 6;
+    if (wave > 0) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        T x, y, z;
+        ib.get(b, x, y, z);
+        red[wave - 1][0][b][lane] = x; red[wave - 1][1][b][lane] = y; red[wave - 1][2][b][lane] = z;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const int li = base + b * kStride;
+        T4 r;
+        ib.get(b, r.x, r.y, r.z);
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { r.x += red[w][0][b][lane]; r.y += red[w][1][b][lane]; r.z += red[w][2][b][lane]; }
+        r.w = (T)0;
+        if (li < a.i_count) out[li] = r;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const int li = base + b * kBlock;
+      if (li < a.i_count) {
+        T4 r;
+        ib.get(b, r.x, r.y, r.z);
+        r.w = (T)0;
+        out[li] = r;
+      }
+    }
+  }
+
+  if constexpr (EPI == EPI_LAST) {
+    // Hand-off between the gridDim.y workgroups of this i-block, placement independent (G16): every storing wave
+    // drains its stores, the workgroup meets, ONE lane releases at agent scope (L2 write-back), waits, and takes a
+    // ticket; whoever draws the last ticket acquires (L1 invalidate), waits, and only then -- behind a barrier -- does
+    // the workgroup read the other workgroups' slabs with plain loads.
+    __shared__ int s_last;
+    __shared__ double ksum[4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler may drop its own wait after buffer_wbl2
+      const unsigned ticket = __hip_atomic_fetch_add(a.arrive + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (ticket + 1u == gridDim.y) ? 1 : 0;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        a.arrive[blockIdx.x] = 0u;  // ready for the next launch (visible at the kernel boundary)
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (s_last) {  // workgroup-uniform
+      constexpr int kPer = WSPLIT ? 1 : B;          // bodies of this i-block per thread
+      const int first = WSPLIT ? blockIdx.x * (64 * B) + t : base;
+      const bool active = WSPLIT ? (t < 64 * B) : true;
+      const int nsplit = gridDim.y;
+      double ke = 0.0;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const int li = first + k * kBlock;
+        if (active && li < a.i_count) {
+          T sx = (T)0, sy = (T)0, sz = (T)0;
+          for (int y = 0; y < nsplit; ++y) {  // split order: the same sum as integrate_kernel
+            const T4 q = a.accp[(size_t)y * a.own_pad + li];
+            sx += q.x; sy += q.y; sz += q.z;
+          }
+          T4 p = a.posm[a.i_begin + li];
+          T4 v = a.velm[li];
+          ke += (double)euler_update<T>(sx, sy, sz, a.dt, p, v);
+          a.velm[li] = v;
+          a.posm_next[a.i_begin + li] = p;
+        }
+      }
+      const double s = block_sum(ke, ksum);
+      if (t == 0) a.ke_part[blockIdx.x] = s;
+    }
   }
 }
 

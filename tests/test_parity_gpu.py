@@ -81,6 +81,47 @@ def test_fused_and_split_steps_agree(nbx):
     assert np.array_equal(traces[0], traces[1])
 
 
+@pytest.mark.parametrize("n,steps", [(2000, 300), (4099, 120), (16384, 60), (65536, 12), (300, 400)])
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_last_arriver_epilogue_is_bit_equal_to_integrate_kernel(nbx, n, steps, variant):
+    """fused_epilogue=1 with j-splits: the last workgroup to reach an i-block sums the slabs and integrates (agent-scope
+    release / ticket / acquire).  A stale slab read would change bits; run many steps, every variant, fp32 and fp64 sizes."""
+    ic = nbx.initial_conditions(n)
+    res = []
+    for fe in (1, 2):
+        with nbx.Context(n, 32, fused_epilogue=fe, kernel_variant=variant, use_graph=2) as c:
+            c.upload(ic)
+            ke = c.step_trace(steps)
+            st = c.stats()
+            res.append((ke, c.download(), st))
+    assert res[0][2]["fused_epilogue"] in (1, 2) and res[1][2]["fused_epilogue"] == 0
+    assert res[0][2]["j_split"] == res[1][2]["j_split"]
+    # energies: same terms, but one fp64 partial per i-block instead of one per 256 bodies => last-bit regrouping only
+    assert rel_err(res[0][0], res[1][0]).max() < 1e-13
+    for f in res[0][1]:
+        assert np.array_equal(res[0][1][f], res[1][1][f]), f
+
+
+def test_last_arriver_epilogue_fp64_and_sharded(nbx):
+    ic = nbx.initial_conditions(4099, 64)
+    out = []
+    for fe in (1, 2):
+        with nbx.Context(4099, 64, fused_epilogue=fe, j_split=5) as c:
+            c.upload(ic)
+            out.append((c.step_trace(50), c.download()))
+    assert rel_err(out[0][0], out[1][0]).max() < 1e-13
+    for f in out[0][1]:
+        assert np.array_equal(out[0][1][f], out[1][1][f]), f
+    with nbx.Group(4099, 32, n_ranks=4, devices=[0] * 4, fused_epilogue=1, j_split=4) as g, \
+            nbx.Group(4099, 32, n_ranks=4, devices=[0] * 4, fused_epilogue=2, j_split=4) as h:
+        g.upload(nbx.initial_conditions(4099))
+        h.upload(nbx.initial_conditions(4099))
+        assert abs(g.step(40) / h.step(40) - 1.0) < 1e-13
+        dg, dh = g.download(), h.download()
+    for f in dg:
+        assert np.array_equal(dg[f], dh[f]), f
+
+
 # ---- kinetic-energy traces against the reference's own output -----------------------------------
 def _trace(nbx, n, steps, precision=32, **opts):
     with nbx.Context(n, precision, **opts) as c:
