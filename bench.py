@@ -84,8 +84,7 @@ def cpu_baseline(kind, n_gpu, precision):
         t = statistics.median(secs[1:]) if len(secs) > 1 else secs[0]
         what = "reference ver7 (unmodified source, g++ -O2 -fopenmp, built in the build container)"
     else:
-        for k, v in (("OMP_NUM_THREADS", str(threads)), ("OMP_PROC_BIND", "spread")):
-            os.environ.setdefault(k, v)
+        os.environ.setdefault("OMP_NUM_THREADS", str(threads))  # no OMP_PROC_BIND here: it would pin THIS process
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import numpy as np
         import oracle as O
