@@ -257,6 +257,20 @@ void GSimulation::start() {
   if (ranks > 1)
     std::cout << "# GPUs / ranks       : " << ranks << " x " << st.i_count << " bodies, position all-gather per step over "
               << (rccl ? "RCCL" : "device-to-device copies") << std::endl;
+  // NBODY_JSON=<file>: the same facts as one machine-readable line (does not touch stdout)
+  if (const char* jp = std::getenv("NBODY_JSON")) {
+    if (FILE* jf = std::fopen(jp, "w")) {
+      const double pps = (_totTime > 0) ? nd * nd * nsteps / _totTime : 0.0;
+      std::fprintf(jf,
+                   "{\"n\": %d, \"steps\": %d, \"precision\": %d, \"ranks\": %d, \"exchange\": \"%s\", \"total_time_s\": %.9g, "
+                   "\"pair_per_s_total\": %.9g, \"gflops_avg_reference_convention\": %.9g, \"kenergy_last_printed\": %.9g, "
+                   "\"kernel\": \"%s\", \"bodies_per_lane\": %d, \"j_split\": %d, \"grid\": [%d, %d], \"device\": \"%s\"}\n",
+                   n, nsteps, st.precision, (int)ranks, ranks > 1 ? (rccl ? "rccl" : "copy") : "none", _totTime, pps, av,
+                   (double)_kenergy, st.kernel_variant == NBX_KERNEL_LDS ? "lds" : st.kernel_variant == NBX_KERNEL_SGPR ? "sgpr" : "sgprw",
+                   st.bodies_per_lane, st.j_split, st.force_grid_x, st.force_grid_y, st.device_name);
+      std::fclose(jf);
+    }
+  }
   if (nf > 2) {
     const double pairs_per_s = av / 29.0 * 1e9;  // GFlops(29/pair) -> pair/s, integration term ignored
     std::cout << "# Pair rate          : " << pairs_per_s * 1e-9 << " G pair/s = "

@@ -506,6 +506,17 @@ def test_cli_default_run_prints_the_reference_table():
     assert lines[i + 5].startswith("# Device") and lines[i + 6].startswith("# Pair rate")
 
 
+def test_cli_json_summary(tmp_path):
+    import subprocess
+    exe = os.path.join(ROOT, "nbody-demo-2023_amd", "host", "nbody.x")
+    out = str(tmp_path / "run.json")
+    p = subprocess.run([exe, "2000", "200"], env=dict(os.environ, NBODY_JSON=out), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0
+    d = json.load(open(out))
+    assert d["n"] == 2000 and d["steps"] == 200 and d["precision"] == 32 and d["ranks"] == 1 and d["kernel"] == "sgprw"
+    assert abs(d["kenergy_last_printed"] - 17.877) < 1e-3 and d["pair_per_s_total"] > 1e9
+
+
 def test_cli_argument_quirks_of_ver7_main():
     # one argument: particles only; three arguments: the step count is silently ignored (argc == 3 test, ver7/main.cpp:36)
     rc, lines, _ = _run_cli("nbody.x", 1000)
