@@ -237,7 +237,7 @@ def main():
             "config": {"workload": workload, "n_bodies": n, "bodies_per_gpu": st["i_count"],
                        "parallelism": "i-block x%d" % a.gpus, "j_tile": st["j_tile"],
                        "bodies_per_lane": st["bodies_per_lane"], "j_split": st["j_split"],
-                       "kernel": {1: "lds", 2: "sgpr", 3: "sgprw"}.get(st["kernel_variant"], "?"),
+                       "kernel": {1: "lds", 2: "sgpr", 3: "sgprw", 4: "exact"}.get(st["kernel_variant"], "?"),
                        "grid": [st["force_grid_x"], st["force_grid_y"]], "block": st["force_block"]},
             "gflops_reference_convention": 1e-9 * (29.0 * pairs_per_step + 19.0 * n) * a.steps / elapsed,
             "kenergy_after_run": ke,

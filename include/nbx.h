@@ -42,7 +42,11 @@ enum {
   NBX_KERNEL_AUTO = 0,  /* = NBX_KERNEL_SGPRW, the fastest measured on MI355X (profiles/r01_kbench_*) */
   NBX_KERNEL_LDS = 1,   /* j-tile (256 records) staged in LDS, broadcast ds_read_b128 (the north-star design) */
   NBX_KERNEL_SGPR = 2,  /* j records fetched by pipelined wave-uniform scalar loads into SGPRs */
-  NBX_KERNEL_SGPRW = 3  /* as SGPR, and the 4 waves of a workgroup share 64*B bodies and split the j range */
+  NBX_KERNEL_SGPRW = 3, /* as SGPR, and the 4 waves of a workgroup share 64*B bodies and split the j range */
+  NBX_KERNEL_EXACT = 4  /* validation only (~50x slower): the arithmetic of the reference's pinned build, bit for bit --
+                           one thread per body, j strictly ascending, unfused IEEE multiply/add in the source's
+                           association, correctly rounded sqrt and divide, G and m multiplied separately.  Positions
+                           and velocities then equal the CPU ver7 run exactly (tests compare CRC-32 of whole arrays) */
 };
 
 typedef struct nbx_ctx nbx_ctx;

@@ -54,6 +54,7 @@ struct nbx_ctx {
   void* accp = nullptr;
   double* ke_part = nullptr;
   unsigned int* arrive = nullptr;  // EPI_LAST arrival counters, one per i-block
+  void* mass_all = nullptr;        // NBX_KERNEL_EXACT only: m of every body (the records carry G*m)
   int ke_parts = 0;       // partials written by the last step
   double* ke_dev = nullptr;  // [ke_cap] reduced sums (sum m v^2)
   int ke_cap = 0;
@@ -141,6 +142,11 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   const int cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
   const int target_wgs = cus * 32;
   int variant = o.kernel_variant;
+  if (variant == NBX_KERNEL_EXACT) {  // one thread per body, no blocking, no splits, separate integrate kernel
+    c->B = 1; c->S = 1; c->jps = c->n_alloc; c->math = MATH_SCALAR; c->variant = variant; c->epi = EPI_SLAB;
+    c->grid = dim3(ceil_div(c->i_count, kBlock), 1);
+    return;
+  }
   if (variant != NBX_KERNEL_LDS && variant != NBX_KERNEL_SGPR && variant != NBX_KERNEL_SGPRW) variant = NBX_KERNEL_SGPRW;
   const int maxB = (c->precision == 32 && variant != NBX_KERNEL_SGPRW) ? 8 : 4;
   int B = o.bodies_per_lane;
@@ -178,6 +184,13 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
 
 template <typename T>
 int enqueue_force(nbx_ctx* c, int epi, double dt) {
+  if (c->variant == NBX_KERNEL_EXACT) {
+    using T4 = typename V4<T>::type;
+    hipLaunchKernelGGL((force_exact_kernel<T>), c->grid, dim3(kBlock), 0, c->stream, (const T4*)c->posm[c->cur],
+                       (const T*)c->mass_all, (T4*)c->accp, c->i_begin, c->i_count, c->n);
+    HIP_TRY(hipGetLastError());
+    return NBX_OK;
+  }
   ForceLauncher<T> fn = pick_force<T>(c, epi);
   if (!fn) return fail(NBX_ERR_ARG, "no kernel instance for this bodies_per_lane / precision");
   ForceArgs<T> a{};
@@ -308,6 +321,7 @@ int upload_t(nbx_ctx* c, const T* px, const T* py, const T* pz, const T* vx, con
   HIP_TRY(hipMemcpyAsync(c->posm[0], hp.data(), sizeof(T4) * hp.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->posm[1], hp.data(), sizeof(T4) * hp.size(), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->velm, hv.data(), sizeof(T4) * hv.size(), hipMemcpyHostToDevice, c->stream));
+  if (c->mass_all) HIP_TRY(hipMemcpyAsync(c->mass_all, m, sizeof(T) * (size_t)c->n, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return NBX_OK;
 }
@@ -441,6 +455,7 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
   const int max_parts = std::max(ceil_div(c->i_count, kBlock), (int)c->grid.x);
   CREATE_TRY(hipMalloc(&c->ke_part, sizeof(double) * (size_t)max_parts));
   CREATE_TRY(hipMalloc(&c->arrive, sizeof(unsigned int) * (size_t)max_parts));
+  if (c->variant == NBX_KERNEL_EXACT) CREATE_TRY(hipMalloc(&c->mass_all, (c->rec / 4) * (size_t)c->n_alloc));
   CREATE_TRY(hipMemsetAsync(c->arrive, 0, sizeof(unsigned int) * (size_t)max_parts, c->stream));
   CREATE_TRY(hipMemsetAsync(c->posm[0], 0, pos_bytes, c->stream));
   CREATE_TRY(hipMemsetAsync(c->posm[1], 0, pos_bytes, c->stream));
@@ -469,6 +484,7 @@ void nbx_destroy(nbx_ctx* c) {
   if (c->accp) (void)hipFree(c->accp);
   if (c->ke_part) (void)hipFree(c->ke_part);
   if (c->arrive) (void)hipFree(c->arrive);
+  if (c->mass_all) (void)hipFree(c->mass_all);
   if (c->ke_dev) (void)hipFree(c->ke_dev);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

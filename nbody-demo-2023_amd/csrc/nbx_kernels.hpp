@@ -93,12 +93,18 @@ __device__ __forceinline__ void pair2(float xj, float yj, float zj, float gmj, f
   az = __builtin_elementwise_fma(dz, s, az);
 }
 
-// Unfused fp32/fp64 multiply-add, so the O(n) update rounds exactly like the reference's
-// x86-64 baseline build (no FMA instruction there).
-__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ double mul_rn(double a, double b) { return __dmul_rn(a, b); }
-__device__ __forceinline__ double add_rn(double a, double b) { return __dadd_rn(a, b); }
+// Separately rounded multiply and add, so the O(n) update rounds exactly like the reference's x86-64 baseline
+// build (no FMA instruction there).  HIP's __fmul_rn / __fadd_rn are plain `*` / `+` and hipcc's
+// default -ffp-contract=fast fuses them (seen in the ISA, caught by the NBX_KERNEL_EXACT bit-equality tests), hence
+// the pragma: it clears the contract flag on exactly these operations and survives inlining.
+template <typename T> __device__ __forceinline__ T mul_rn(T a, T b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+template <typename T> __device__ __forceinline__ T add_rn(T a, T b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
 
 // Sum of one double per thread over the 256-thread workgroup, fixed order: wave64 shuffle tree,
 // then the four wave sums through LDS.  Result valid in thread 0.
@@ -423,6 +429,40 @@ __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> 
       if (t == 0) a.ke_part[blockIdx.x] = s;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// force_exact_kernel (NBX_KERNEL_EXACT): the reference's acceleration loop with the reference's rounding.
+// The pinned build of ver7 (g++ -O2, x86-64 baseline) compiles ver7/GSimulation.cpp:153-173 to a scalar,
+// strictly sequential loop: r2 = ((dx*dx + dy*dy) + dz*dz) + eps, inv = 1.0f / sqrtf(r2) (IEEE sqrtss, divss),
+// term = ((((d*G)*m)*inv)*inv)*inv, sum += term for j = 0..n-1, acc = 0 + sum.  One thread per body does exactly
+// that: contraction off, HIP's correctly rounded fp32 sqrt and divide.  Validation path, not a fast path.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void force_exact_kernel(const typename V4<T>::type* __restrict__ posm,
+                                                             const T* __restrict__ mass,
+                                                             typename V4<T>::type* __restrict__ accp, int i_begin,
+                                                             int i_count, int n) {
+#pragma clang fp contract(off)
+  using T4 = typename V4<T>::type;
+  const int li = blockIdx.x * kBlock + threadIdx.x;
+  if (li >= i_count) return;
+  const T4 pi = posm[i_begin + li];
+  const T eps = softening2<T>(), G = grav_const<T>();
+  T sx = (T)0, sy = (T)0, sz = (T)0;
+  for (int j = 0; j < n; ++j) {
+    const T4 pj = posm[j];
+    const T m = mass[j];
+    const T dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+    const T r2 = ((dx * dx + dy * dy) + dz * dz) + eps;
+    const T inv = (T)1 / sqrt(r2);
+    sx = sx + ((((dx * G) * m) * inv) * inv) * inv;
+    sy = sy + ((((dy * G) * m) * inv) * inv) * inv;
+    sz = sz + ((((dz * G) * m) * inv) * inv) * inv;
+  }
+  T4 r;
+  r.x = (T)0 + sx; r.y = (T)0 + sy; r.z = (T)0 + sz; r.w = (T)0;
+  accp[li] = r;
 }
 
 // ---------------------------------------------------------------------------------------------

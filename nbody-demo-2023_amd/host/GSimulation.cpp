@@ -157,6 +157,7 @@ void GSimulation::start() {
   if (kv && !std::strcmp(kv, "sgpr")) opts.kernel_variant = NBX_KERNEL_SGPR;
   if (kv && !std::strcmp(kv, "lds")) opts.kernel_variant = NBX_KERNEL_LDS;
   if (kv && !std::strcmp(kv, "sgprw")) opts.kernel_variant = NBX_KERNEL_SGPRW;
+  if (kv && !std::strcmp(kv, "exact")) opts.kernel_variant = NBX_KERNEL_EXACT;  // bit-for-bit the CPU ver7 arithmetic
 
   // NBODY_GPUS=k: block-partition the bodies over k GPUs of this node (one all-gather of positions per step);
   // k larger than the device count gives logical ranks sharing devices.  Default: one context on one GPU.
@@ -251,7 +252,7 @@ void GSimulation::start() {
   std::cout << "===============================" << std::endl;
   // extra lines AFTER the reference's footer, so line-wise diffs of the reference part still match
   std::cout << "# Device             : " << st.device_name << " (" << st.cu_count << " CUs), fp" << st.precision
-            << ", kernel " << (st.kernel_variant == NBX_KERNEL_LDS ? "lds" : st.kernel_variant == NBX_KERNEL_SGPR ? "sgpr" : "sgprw")
+            << ", kernel " << (st.kernel_variant == NBX_KERNEL_LDS ? "lds" : st.kernel_variant == NBX_KERNEL_SGPR ? "sgpr" : st.kernel_variant == NBX_KERNEL_EXACT ? "exact" : "sgprw")
             << ", bodies/lane " << st.bodies_per_lane << ", j-split " << st.j_split << ", grid " << st.force_grid_x << "x"
             << st.force_grid_y << std::endl;
   if (ranks > 1)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NBX_LIB") or os.path.join(_HERE, "libnbx.so")
 
 NBX_OK, NBX_ERR_ARG, NBX_ERR_DEVICE, NBX_ERR_STATE, NBX_ERR_ALLOC = 0, -1, -2, -3, -4
-KERNEL_AUTO, KERNEL_LDS, KERNEL_SGPR, KERNEL_SGPRW = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_LDS, KERNEL_SGPR, KERNEL_SGPRW, KERNEL_EXACT = 0, 1, 2, 3, 4
 
 # every symbol include/nbx.h declares (tests check the library exports each of them)
 SYMBOLS = (

@@ -35,6 +35,9 @@ CASES = [
     ("f64", 4099, 40),
     ("f64", 16384, 60),
 ]
+# BASELINE.json configs[2] / configs[4] size: ~65 s per step here, generated once with
+#   python oracle/gen_golden.py --only f32:262144:7 f64:262144:3
+BIG_CASES = [("f32", 262144, 7), ("f64", 262144, 3)]
 
 
 def run_case(prec, n, steps, nsample=8):

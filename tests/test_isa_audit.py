@@ -114,3 +114,15 @@ def test_hot_loop_uses_raw_rsq_and_packed_math(kernels):
         assert "v_rsq_f32" in body and "v_div_scale" not in body and "v_sqrt_f32" not in body, name
         if re.search(r"force_kernelIfLi[248]ELi\dELb[01]ELi1ELi1E", name):  # MATH_PACKED instances
             assert "v_pk_fma_f32" in body and "v_pk_mul_f32" in body, name
+
+
+def test_euler_update_is_not_fma_contracted(kernels):
+    """The reference's build has no FMA; hipcc fuses `a*b + c` by default.  integrate_kernel (fp32 and fp64) must keep
+    the multiply and the add separately rounded -- the NBX_KERNEL_EXACT bit-equality tests depend on it."""
+    seen = 0
+    for name, (body, _) in kernels.items():
+        if "integrate_kernel" not in name:
+            continue
+        seen += 1
+        assert not re.search(r"\bv_(pk_)?fma(c|ak|mk)?_f(32|64)\b", body), name
+    assert seen == 2
