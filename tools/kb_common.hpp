@@ -16,3 +16,4 @@ struct Variant {
 };
 void reg_slp(std::vector<Variant>&);
 void reg_noslp(std::vector<Variant>&);
+void reg_sym(std::vector<Variant>&);

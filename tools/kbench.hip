@@ -62,6 +62,7 @@ int main(int argc, char** argv) {
   std::vector<Variant> base, vs;
   reg_noslp(base);
   reg_slp(base);
+  if (n % 1024 == 0 && n >= 8192) reg_sym(vs);  // experimental symmetric kernel: S fixed at 1 (its launcher ignores the grid)
   for (auto& b : base)
     for (int S : splits) {
       if (S > n / (b.B < 0 ? 64 : kTile)) continue;
