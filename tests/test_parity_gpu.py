@@ -756,3 +756,21 @@ def test_fast_kernels_differ_from_exact_mode_only_by_rounding(nbx):
     for k in (nbx.KERNEL_SGPRW, nbx.KERNEL_LDS):
         worst = max(np.abs(a - b).max() for a, b in zip(acc[k], acc[nbx.KERNEL_EXACT])) / scale
         assert 0 < worst < 2e-5, (k, worst)
+
+
+def test_throughput_floors_other_configs(nbx):
+    """Regression floors (well under the measured round-1 figures in profiles/r01_sweep_*): config 1's n, a mid n, fp64."""
+    import time
+    floors = [(16384, 32, 0.30), (65536, 32, 0.45), (65536, 64, 0.35)]
+    for n, prec, floor in floors:
+        with nbx.Context(n, prec) as c:
+            c.upload(nbx.initial_conditions(n, prec))
+            c.step(5, kenergy=False)
+            c.sync()
+            steps = 200 if n == 16384 else 30
+            t0 = time.perf_counter()
+            c.step(steps, kenergy=False)
+            c.sync()
+            dt = time.perf_counter() - t0
+        frac = 20.0 * float(n) * n * steps / dt / (157.3e12 if prec == 32 else 78.6e12)
+        assert frac > floor, (n, prec, frac)
