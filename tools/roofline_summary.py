@@ -33,6 +33,12 @@ def per_kernel(path, match):
     return out, (sum(dur) / len(dur) / 1e6 if dur else None), meta
 
 
+def newest(pattern):
+    """gpurun merges every run into the same directories: take the most recent file that matches."""
+    f = glob.glob(pattern)
+    return [max(f, key=os.path.getmtime)] if f else []
+
+
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 262144
@@ -45,14 +51,14 @@ def main():
     os.makedirs(dst, exist_ok=True)
     match = "force_kernel"
 
-    stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+    stats = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
     rows = []
     if stats:
         shutil.copy(stats[0], os.path.join(dst, "%s_kernel_stats.csv" % tag))
         rows = list(csv.DictReader(open(stats[0])))
     counters, meta, durs = {}, {}, {}
     for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm"):
-        f = glob.glob(os.path.join(src, d, "*", "*_counter_collection.csv"))
+        f = newest(os.path.join(src, d, "*", "*_counter_collection.csv"))
         if not f:
             continue
         c, ms, m = per_kernel(f[0], match)
