@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--bodies-per-lane", type=int, default=0)
     ap.add_argument("--j-split", type=int, default=0)
     ap.add_argument("--kernel", default="auto", choices=("auto", "lds", "sgpr", "sgprw"))
+    ap.add_argument("--order", default="auto", choices=("auto", "reference", "tree"),
+                    help="summation order of a body's pair terms (include/nbx.h): reference = the CPU loop's order")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,7 +171,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    opts = dict(bodies_per_lane=a.bodies_per_lane, j_split=a.j_split,
+    opts = dict(bodies_per_lane=a.bodies_per_lane, j_split=a.j_split, summation_order={"auto": 0, "reference": 1, "tree": 2}[a.order],
                 kernel_variant={"auto": 0, "lds": 1, "sgpr": 2, "sgprw": 3}[a.kernel])
 
     parity = parity_probe(nbx, n, a.precision) if (rank == 0 and world == 1) else None
@@ -203,6 +205,26 @@ def main():
     # N == 1 only: the multi-GPU runs use configs[3]'s n = 1048576; time a few steps of it on this one GPU as
     # well, so that scaling can also be read at equal n (pair/s is nearly flat in n here, see profiles/r01_sweep_*)
     same_n = None
+    other_order = None
+    if world == 1 and a.order == "auto" and not a.j_split and a.kernel in ("auto",):
+        # the same workload with the OTHER summation order (see DESIGN.md "Summation order"): reference order is what
+        # matches CPU ver7's kenergy at this size, tree order is the fastest and the closest to an fp64 sum
+        alt = 2 if st["summation_order"] == 1 else 1
+        o2 = dict(opts, summation_order=alt)
+        s2 = sharded.ShardedSimulation(n, a.precision, dist=None, **o2)
+        s2.upload(ic)
+        s2.step(a.warmup)
+        s2.sync()
+        tb = time.perf_counter()
+        s2.step(a.steps)
+        s2.sync()
+        el2 = time.perf_counter() - tb
+        st2 = s2.engine.ctx.stats()
+        other_order = {"summation_order": {1: "reference", 2: "tree"}[alt], "value": float(n) * n * a.steps / el2, "unit": "pair/s",
+                       "roofline_frac": FLOP_PER_PAIR * float(n) * n * a.steps / el2 / ((PEAK_FP32_VECTOR_TFLOPS if a.precision == 32 else PEAK_FP64_VECTOR_TFLOPS) * 1e12),
+                       "kernel": {1: "lds", 2: "sgpr", 3: "sgprw"}.get(st2["kernel_variant"], "?"), "bodies_per_lane": st2["bodies_per_lane"],
+                       "j_split": st2["j_split"]}
+        s2.close()
     if world == 1 and not a.n and a.precision == 32:
         big = sharded.ShardedSimulation(1048576, 32, dist=None, **opts)
         big.upload(nbx.initial_conditions(1048576, 32))
@@ -237,6 +259,7 @@ def main():
             "config": {"workload": workload, "n_bodies": n, "bodies_per_gpu": st["i_count"],
                        "parallelism": "i-block x%d" % a.gpus, "j_tile": st["j_tile"],
                        "bodies_per_lane": st["bodies_per_lane"], "j_split": st["j_split"],
+                       "summation_order": {1: "reference", 2: "tree"}.get(st["summation_order"], "?"),
                        "kernel": {1: "lds", 2: "sgpr", 3: "sgprw", 4: "exact"}.get(st["kernel_variant"], "?"),
                        "grid": [st["force_grid_x"], st["force_grid_y"]], "block": st["force_block"]},
             "gflops_reference_convention": 1e-9 * (29.0 * pairs_per_step + 19.0 * n) * a.steps / elapsed,
@@ -253,6 +276,8 @@ def main():
             line["parity"] = parity
         if same_n:
             line["one_gpu_at_multi_gpu_n"] = same_n
+        if other_order:
+            line["other_summation_order"] = other_order
         if cpu:
             line["cpu_baseline"] = cpu
             line["gpu_over_cpu"] = value / cpu["value"]

@@ -37,16 +37,21 @@ enum {
   NBX_ERR_ALLOC = -4
 };
 
+enum { NBX_ORDER_AUTO = 0, NBX_ORDER_REFERENCE = 1, NBX_ORDER_TREE = 2 };
+
 /* kernel_variant values */
 enum {
   NBX_KERNEL_AUTO = 0,  /* = NBX_KERNEL_SGPRW, the fastest measured on MI355X (profiles/r01_kbench_*) */
   NBX_KERNEL_LDS = 1,   /* j-tile (256 records) staged in LDS, broadcast ds_read_b128 (the north-star design) */
   NBX_KERNEL_SGPR = 2,  /* j records fetched by pipelined wave-uniform scalar loads into SGPRs */
   NBX_KERNEL_SGPRW = 3, /* as SGPR, and the 4 waves of a workgroup share 64*B bodies and split the j range */
-  NBX_KERNEL_EXACT = 4  /* validation only (~50x slower): the arithmetic of the reference's pinned build, bit for bit --
+  NBX_KERNEL_EXACT = 4, /* validation only (~50x slower): the arithmetic of the reference's pinned build, bit for bit --
                            one thread per body, j strictly ascending, unfused IEEE multiply/add in the source's
                            association, correctly rounded sqrt and divide, G and m multiplied separately.  Positions
                            and velocities then equal the CPU ver7 run exactly (tests compare CRC-32 of whole arrays) */
+  NBX_KERNEL_EXACT_FMA = 5 /* diagnostic: NBX_KERNEL_EXACT with FMA contraction allowed -- what a -march=native / icpc -xAVX2
+                           build of the same reference loop computes.  Used to show how far two builds of the REFERENCE
+                           drift apart in the chaotic regime (tools/validate_big.py) */
 };
 
 typedef struct nbx_ctx nbx_ctx;
@@ -74,13 +79,24 @@ typedef struct nbx_opts {
                               integrate kernel */
   int32_t use_graph;       /* 0 = auto, 1 = replay multi-step windows from a hipGraph, 2 = plain launches */
   int32_t external_stream; /* 0 = own non-blocking stream; 1 = enqueue everything on `stream` (caller-owned) */
-  int32_t reserved[4];
+  int32_t summation_order; /* how a body's n pair terms are added up:
+                              1 = NBX_ORDER_REFERENCE: one fp32 (fp64) accumulator per body, j strictly ascending, exactly the
+                                  reference's loop order (ver7/GSimulation.cpp:156-173).  Reproduces the reference's own
+                                  rounding noise, which at n >= 262144 shifts kenergy by 5e-4..1e-3: measured against the
+                                  bit-exact NBX_KERNEL_EXACT, kenergy stays within 5e-5 (n=262144 x 200 steps) / 5e-7
+                                  (n=1048576 x 100); needs j_split = 1, so parallelism = owned bodies
+                              2 = NBX_ORDER_TREE: partial sums per wave and per j-split, added in fixed order: fastest and
+                                  ~40x closer to an fp64 sum, but NOT the reference's rounding
+                              0 = auto: REFERENCE when the context owns >= 131072 bodies (enough to fill the GPU), TREE below
+                                  (there the two agree with the reference within the 1e-4 gate) */
+  int32_t reserved[3];
 } nbx_opts;
 
 typedef struct nbx_stats_t {
   int32_t n, n_alloc, i_begin, i_count, precision;
   int32_t bodies_per_lane, j_split, j_tile, kernel_variant;
   int32_t fused_epilogue;      /* 0 separate integrate kernel, 1 integrated directly (one split), 2 last-arriver */
+  int32_t summation_order;     /* NBX_ORDER_REFERENCE or NBX_ORDER_TREE actually in use */
   int32_t force_grid_x, force_grid_y, force_block;
   int32_t cu_count, clock_mhz;
   int64_t steps_done;          /* time steps executed since create */

@@ -43,7 +43,7 @@ constexpr int kMaxProfiledLaunches = 8192;
 
 struct nbx_ctx {
   int n = 0, n_alloc = 0, i_begin = 0, i_count = 0, own_pad = 0, precision = 32;
-  int B = 1, S = 1, jps = 0, variant = NBX_KERNEL_LDS, epi = EPI_SLAB, math = MATH_SCALAR;
+  int B = 1, S = 1, jps = 0, variant = NBX_KERNEL_LDS, epi = EPI_SLAB, math = MATH_SCALAR, order = NBX_ORDER_TREE;
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -142,9 +142,33 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   const int cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
   const int target_wgs = cus * 32;
   int variant = o.kernel_variant;
-  if (variant == NBX_KERNEL_EXACT) {  // one thread per body, no blocking, no splits, separate integrate kernel
+  if (variant == NBX_KERNEL_EXACT || variant == NBX_KERNEL_EXACT_FMA) {  // one thread per body, no blocking, no splits, separate integrate kernel
     c->B = 1; c->S = 1; c->jps = c->n_alloc; c->math = MATH_SCALAR; c->variant = variant; c->epi = EPI_SLAB;
     c->grid = dim3(ceil_div(c->i_count, kBlock), 1);
+    return;
+  }
+  // Summation order (include/nbx.h).  The reference adds a body's n terms one after the other into one fp32
+  // accumulator; at n >= 262144 that sum carries ~1e-5 of rounding noise per step which heats the system (kenergy
+  // +5e-4..1e-3 against an fp64 run).  A tree of partial sums does not reproduce that, a single accumulator per body
+  // in the same j order does (to 5e-5 / 5e-7, tools/validate_big.py) -- at the price of one chain per owned body.
+  int order = o.summation_order;
+  if (order != NBX_ORDER_REFERENCE && order != NBX_ORDER_TREE) {
+    const bool shape_given = o.j_split > 0 || variant == NBX_KERNEL_SGPRW;
+    if (o.j_split == 1 && variant != NBX_KERNEL_SGPRW) order = NBX_ORDER_REFERENCE;
+    else order = (!shape_given && c->i_count >= 131072) ? NBX_ORDER_REFERENCE : NBX_ORDER_TREE;
+  }
+  c->order = order;
+  if (order == NBX_ORDER_REFERENCE) {
+    if (variant != NBX_KERNEL_LDS && variant != NBX_KERNEL_SGPR) variant = NBX_KERNEL_SGPR;
+    int B = o.bodies_per_lane;
+    const int maxBr = c->precision == 32 ? 8 : 4;
+    if (B != 1 && B != 2 && B != 4 && B != 8) B = 0;
+    if (B > maxBr) B = maxBr;
+    if (B == 0) B = c->i_count >= 393216 ? 4 : 2;  // measured: tools/seq_shapes.py
+    c->B = B; c->S = 1; c->jps = c->n_alloc; c->variant = variant;
+    c->math = (c->precision == 32 && B >= 2) ? MATH_PACKED : MATH_SCALAR;
+    c->epi = o.fused_epilogue == 2 ? EPI_SLAB : EPI_ROW;
+    c->grid = dim3(ceil_div(c->i_count, kBlock * B), 1);
     return;
   }
   if (variant != NBX_KERNEL_LDS && variant != NBX_KERNEL_SGPR && variant != NBX_KERNEL_SGPRW) variant = NBX_KERNEL_SGPRW;
@@ -184,10 +208,14 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
 
 template <typename T>
 int enqueue_force(nbx_ctx* c, int epi, double dt) {
-  if (c->variant == NBX_KERNEL_EXACT) {
+  if (c->variant == NBX_KERNEL_EXACT || c->variant == NBX_KERNEL_EXACT_FMA) {
     using T4 = typename V4<T>::type;
-    hipLaunchKernelGGL((force_exact_kernel<T>), c->grid, dim3(kBlock), 0, c->stream, (const T4*)c->posm[c->cur],
-                       (const T*)c->mass_all, (T4*)c->accp, c->i_begin, c->i_count, c->n);
+    if (c->variant == NBX_KERNEL_EXACT)
+      hipLaunchKernelGGL((force_exact_kernel<T, false>), c->grid, dim3(kBlock), 0, c->stream, (const T4*)c->posm[c->cur],
+                         (const T*)c->mass_all, (T4*)c->accp, c->i_begin, c->i_count, c->n);
+    else
+      hipLaunchKernelGGL((force_exact_kernel<T, true>), c->grid, dim3(kBlock), 0, c->stream, (const T4*)c->posm[c->cur],
+                         (const T*)c->mass_all, (T4*)c->accp, c->i_begin, c->i_count, c->n);
     HIP_TRY(hipGetLastError());
     return NBX_OK;
   }
@@ -455,7 +483,7 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
   const int max_parts = std::max(ceil_div(c->i_count, kBlock), (int)c->grid.x);
   CREATE_TRY(hipMalloc(&c->ke_part, sizeof(double) * (size_t)max_parts));
   CREATE_TRY(hipMalloc(&c->arrive, sizeof(unsigned int) * (size_t)max_parts));
-  if (c->variant == NBX_KERNEL_EXACT) CREATE_TRY(hipMalloc(&c->mass_all, (c->rec / 4) * (size_t)c->n_alloc));
+  if (c->variant == NBX_KERNEL_EXACT || c->variant == NBX_KERNEL_EXACT_FMA) CREATE_TRY(hipMalloc(&c->mass_all, (c->rec / 4) * (size_t)c->n_alloc));
   CREATE_TRY(hipMemsetAsync(c->arrive, 0, sizeof(unsigned int) * (size_t)max_parts, c->stream));
   CREATE_TRY(hipMemsetAsync(c->posm[0], 0, pos_bytes, c->stream));
   CREATE_TRY(hipMemsetAsync(c->posm[1], 0, pos_bytes, c->stream));
@@ -692,7 +720,7 @@ int nbx_stats(nbx_ctx* c, nbx_stats_t* s) {
   std::memset(s, 0, sizeof(*s));
   s->n = c->n; s->n_alloc = c->n_alloc; s->i_begin = c->i_begin; s->i_count = c->i_count;
   s->precision = c->precision; s->bodies_per_lane = c->B; s->j_split = c->S; s->j_tile = kTile;
-  s->kernel_variant = c->variant; s->fused_epilogue = c->epi;
+  s->kernel_variant = c->variant; s->fused_epilogue = c->epi; s->summation_order = c->order;
   s->force_grid_x = c->grid.x; s->force_grid_y = c->grid.y; s->force_block = kBlock;
   s->cu_count = c->prop.multiProcessorCount; s->clock_mhz = c->prop.clockRate / 1000;
   s->steps_done = c->steps_done;

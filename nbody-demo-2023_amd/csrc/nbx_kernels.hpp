@@ -438,32 +438,46 @@ __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> 
 // term = ((((d*G)*m)*inv)*inv)*inv, sum += term for j = 0..n-1, acc = 0 + sum.  One thread per body does exactly
 // that: contraction off, HIP's correctly rounded fp32 sqrt and divide.  Validation path, not a fast path.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+// The reference's loop body, spelled once; the fp-contract pragma is lexical, so the text is instantiated inside
+// each pragma's scope below.
+#define NBX_EXACT_ROW()                                                            \
+  T sx = (T)0, sy = (T)0, sz = (T)0;                                               \
+  for (int j = 0; j < n; ++j) {                                                    \
+    const T4 pj = posm[j];                                                         \
+    const T m = mass[j];                                                           \
+    const T dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;                  \
+    const T r2 = ((dx * dx + dy * dy) + dz * dz) + eps;                            \
+    const T inv = (T)1 / sqrt(r2);                                                 \
+    sx = sx + ((((dx * G) * m) * inv) * inv) * inv;                                \
+    sy = sy + ((((dy * G) * m) * inv) * inv) * inv;                                \
+    sz = sz + ((((dz * G) * m) * inv) * inv) * inv;                                \
+  }                                                                                \
+  r.x = (T)0 + sx; r.y = (T)0 + sy; r.z = (T)0 + sz;
+
+// CONTRACT = false: contraction off (the pinned reference build).  CONTRACT = true: the same source lines with FMA
+// contraction allowed, i.e. another legitimate build of the reference (diagnostic NBX_KERNEL_EXACT_FMA).
+template <typename T, bool CONTRACT>
 __global__ __launch_bounds__(kBlock) void force_exact_kernel(const typename V4<T>::type* __restrict__ posm,
                                                              const T* __restrict__ mass,
                                                              typename V4<T>::type* __restrict__ accp, int i_begin,
                                                              int i_count, int n) {
-#pragma clang fp contract(off)
   using T4 = typename V4<T>::type;
   const int li = blockIdx.x * kBlock + threadIdx.x;
   if (li >= i_count) return;
   const T4 pi = posm[i_begin + li];
   const T eps = softening2<T>(), G = grav_const<T>();
-  T sx = (T)0, sy = (T)0, sz = (T)0;
-  for (int j = 0; j < n; ++j) {
-    const T4 pj = posm[j];
-    const T m = mass[j];
-    const T dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
-    const T r2 = ((dx * dx + dy * dy) + dz * dz) + eps;
-    const T inv = (T)1 / sqrt(r2);
-    sx = sx + ((((dx * G) * m) * inv) * inv) * inv;
-    sy = sy + ((((dy * G) * m) * inv) * inv) * inv;
-    sz = sz + ((((dz * G) * m) * inv) * inv) * inv;
-  }
   T4 r;
-  r.x = (T)0 + sx; r.y = (T)0 + sy; r.z = (T)0 + sz; r.w = (T)0;
+  r.w = (T)0;
+  if constexpr (CONTRACT) {
+#pragma clang fp contract(fast)
+    NBX_EXACT_ROW()
+  } else {
+#pragma clang fp contract(off)
+    NBX_EXACT_ROW()
+  }
   accp[li] = r;
 }
+#undef NBX_EXACT_ROW
 
 // ---------------------------------------------------------------------------------------------
 // integrate_kernel: one body per thread; sums the S partial accelerations in split order.

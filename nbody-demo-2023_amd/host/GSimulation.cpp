@@ -159,6 +159,12 @@ void GSimulation::start() {
   if (kv && !std::strcmp(kv, "sgprw")) opts.kernel_variant = NBX_KERNEL_SGPRW;
   if (kv && !std::strcmp(kv, "exact")) opts.kernel_variant = NBX_KERNEL_EXACT;  // bit-for-bit the CPU ver7 arithmetic
 
+  // NBODY_ORDER=reference|tree: how each body's pair terms are summed (include/nbx.h summation_order); default auto
+  if (const char* ord = std::getenv("NBODY_ORDER")) {
+    if (!std::strcmp(ord, "reference")) opts.summation_order = NBX_ORDER_REFERENCE;
+    if (!std::strcmp(ord, "tree")) opts.summation_order = NBX_ORDER_TREE;
+  }
+
   // NBODY_GPUS=k: block-partition the bodies over k GPUs of this node (one all-gather of positions per step);
   // k larger than the device count gives logical ranks sharing devices.  Default: one context on one GPU.
   const int gpus = env_int("NBODY_GPUS", 1);
@@ -253,6 +259,7 @@ void GSimulation::start() {
   // extra lines AFTER the reference's footer, so line-wise diffs of the reference part still match
   std::cout << "# Device             : " << st.device_name << " (" << st.cu_count << " CUs), fp" << st.precision
             << ", kernel " << (st.kernel_variant == NBX_KERNEL_LDS ? "lds" : st.kernel_variant == NBX_KERNEL_SGPR ? "sgpr" : st.kernel_variant == NBX_KERNEL_EXACT ? "exact" : "sgprw")
+            << ", " << (st.summation_order == NBX_ORDER_REFERENCE ? "reference-order" : "tree") << " sums"
             << ", bodies/lane " << st.bodies_per_lane << ", j-split " << st.j_split << ", grid " << st.force_grid_x << "x"
             << st.force_grid_y << std::endl;
   if (ranks > 1)

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NBX_LIB") or os.path.join(_HERE, "libnbx.so")
 
 NBX_OK, NBX_ERR_ARG, NBX_ERR_DEVICE, NBX_ERR_STATE, NBX_ERR_ALLOC = 0, -1, -2, -3, -4
-KERNEL_AUTO, KERNEL_LDS, KERNEL_SGPR, KERNEL_SGPRW, KERNEL_EXACT = 0, 1, 2, 3, 4
+ORDER_AUTO, ORDER_REFERENCE, ORDER_TREE = 0, 1, 2
+KERNEL_AUTO, KERNEL_LDS, KERNEL_SGPR, KERNEL_SGPRW, KERNEL_EXACT, KERNEL_EXACT_FMA = 0, 1, 2, 3, 4, 5
 
 # every symbol include/nbx.h declares (tests check the library exports each of them)
 SYMBOLS = (
@@ -38,7 +39,7 @@ class Opts(ctypes.Structure):
         ("i_begin", ctypes.c_int32), ("i_count", ctypes.c_int32), ("n_alloc", ctypes.c_int32),
         ("bodies_per_lane", ctypes.c_int32), ("j_split", ctypes.c_int32), ("kernel_variant", ctypes.c_int32),
         ("fused_epilogue", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("external_stream", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 4),
+        ("summation_order", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3),
     ]
 
 
@@ -46,7 +47,7 @@ class Stats(ctypes.Structure):
     _fields_ = [
         ("n", ctypes.c_int32), ("n_alloc", ctypes.c_int32), ("i_begin", ctypes.c_int32), ("i_count", ctypes.c_int32),
         ("precision", ctypes.c_int32), ("bodies_per_lane", ctypes.c_int32), ("j_split", ctypes.c_int32),
-        ("j_tile", ctypes.c_int32), ("kernel_variant", ctypes.c_int32), ("fused_epilogue", ctypes.c_int32),
+        ("j_tile", ctypes.c_int32), ("kernel_variant", ctypes.c_int32), ("fused_epilogue", ctypes.c_int32), ("summation_order", ctypes.c_int32),
         ("force_grid_x", ctypes.c_int32), ("force_grid_y", ctypes.c_int32), ("force_block", ctypes.c_int32),
         ("cu_count", ctypes.c_int32), ("clock_mhz", ctypes.c_int32), ("steps_done", ctypes.c_int64),
         ("force_launches_timed", ctypes.c_int64), ("force_ms_total", ctypes.c_double),

@@ -18,9 +18,9 @@ import nbx  # noqa: E402
 PEAK = {32: 157.3e12, 64: 78.6e12}
 
 
-def time_steps(n, precision, target_s=1.0):
+def time_steps(n, precision, target_s=1.0, order=0):
     ic = nbx.initial_conditions(n, precision)
-    with nbx.Context(n, precision) as c:
+    with nbx.Context(n, precision, summation_order=order) as c:
         c.upload(ic)
         c.step(3, kenergy=False)
         c.sync()
@@ -40,7 +40,8 @@ def time_steps(n, precision, target_s=1.0):
             "roofline_frac": 20.0 * float(n) * n * steps / wall / PEAK[precision],
             "force_kernel_us": 1e3 * kms, "force_kernel_frac": 20.0 * float(n) * n / (kms * 1e-3) / PEAK[precision] if kms else None,
             "bodies_per_lane": st["bodies_per_lane"], "j_split": st["j_split"], "grid": [st["force_grid_x"], st["force_grid_y"]],
-            "kernel": {1: "lds", 2: "sgpr", 3: "sgprw"}[st["kernel_variant"]]}
+            "kernel": {1: "lds", 2: "sgpr", 3: "sgprw"}[st["kernel_variant"]],
+            "order": {1: "reference", 2: "tree"}[st["summation_order"]]}
 
 
 def main():
@@ -48,16 +49,17 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sweep.json"))
     ap.add_argument("--max-n", type=int, default=1048576)
     ap.add_argument("--precision", type=int, default=32)
+    ap.add_argument("--order", default="auto", choices=("auto", "reference", "tree"))
     a = ap.parse_args()
     rows = []
     n = 2048
     print("%9s %8s %12s %14s %9s %12s %9s  shape" % ("n", "steps", "us/step", "G pair/s", "roof %", "kernel us", "kern %"))
     while n <= a.max_n:
-        r = time_steps(n, a.precision)
+        r = time_steps(n, a.precision, order={"auto": 0, "reference": 1, "tree": 2}[a.order])
         rows.append(r)
-        print("%9d %8d %12.1f %14.1f %9.2f %12.1f %9.2f  %s B%d S%d %dx%d" % (
+        print("%9d %8d %12.1f %14.1f %9.2f %12.1f %9.2f  %s %s B%d S%d %dx%d" % (
             r["n"], r["steps"], r["us_per_step"], r["pair_per_s"] * 1e-9, 100 * r["roofline_frac"], r["force_kernel_us"],
-            100 * (r["force_kernel_frac"] or 0), r["kernel"], r["bodies_per_lane"], r["j_split"], r["grid"][0], r["grid"][1]), flush=True)
+            100 * (r["force_kernel_frac"] or 0), r["order"], r["kernel"], r["bodies_per_lane"], r["j_split"], r["grid"][0], r["grid"][1]), flush=True)
         n *= 2
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump({"precision": a.precision, "peak_flops": PEAK[a.precision], "flop_per_pair": 20, "rows": rows}, open(a.out, "w"), indent=1)
