@@ -95,10 +95,15 @@ ForceLauncher<T> pick_b(int B) {
     case 1:
       if constexpr (MATH == MATH_SCALAR) return launch_force_t<T, 1, JSRC, EPI, MATH, WS>;
       return nullptr;
-    case 2: return launch_force_t<T, 2, JSRC, EPI, MATH, WS>;
-    case 4: return launch_force_t<T, 4, JSRC, EPI, MATH, WS>;
+    // fp32 runs B >= 2 on the packed pipe only: the scalar-math B >= 2 instances are not built
+    case 2:
+      if constexpr (sizeof(T) == 8 || MATH == MATH_PACKED) return launch_force_t<T, 2, JSRC, EPI, MATH, WS>;
+      return nullptr;
+    case 4:
+      if constexpr (sizeof(T) == 8 || MATH == MATH_PACKED) return launch_force_t<T, 4, JSRC, EPI, MATH, WS>;
+      return nullptr;
     case 8:
-      if constexpr (sizeof(T) == 4 && !WS) return launch_force_t<T, 8, JSRC, EPI, MATH, WS>;
+      if constexpr (sizeof(T) == 4 && !WS && MATH == MATH_PACKED) return launch_force_t<T, 8, JSRC, EPI, MATH, WS>;
       return nullptr;
   }
   return nullptr;
@@ -179,7 +184,7 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   if (B == 0) B = c->i_count >= 16384 ? 4 : 2;
   const int iblk = (variant == NBX_KERNEL_SGPRW ? 64 : kBlock) * B;  // bodies per workgroup
   // j-range granularity of one split: a whole LDS tile / two pipelined SGPR batches (per wave)
-  const int gran = variant == NBX_KERNEL_LDS ? kTile : (variant == NBX_KERNEL_SGPRW ? 32 : 16);
+  const int gran = variant == NBX_KERNEL_LDS ? kTile : (variant == NBX_KERNEL_SGPRW ? 32 : 32);
   const int max_split = std::max(1, c->n_alloc / gran);
   int S = o.j_split;
   if (S <= 0) {

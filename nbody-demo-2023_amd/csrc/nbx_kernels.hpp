@@ -144,7 +144,7 @@ struct ForceArgs {
   unsigned int* arrive;              // EPI_LAST: one arrival counter per i-block, zero between launches
   int i_begin, i_count, own_pad;
   int j_per_split;                   // split y covers [y*jps, min((y+1)*jps, n_alloc)); multiple of kTile for the
-                                     // LDS source, of 2*kSgprBatch (x4 under WSPLIT) for the SGPR source
+                                     // LDS source, of 4*kSgprBatch (2*kSgprBatch per wave under WSPLIT) for the SGPR one
   int n_alloc;                       // multiple of kTile
   T dt;
 };
@@ -185,6 +185,13 @@ template <> struct SgprBatch<double> {
   __device__ __forceinline__ double z(int u) const { return r[4 * u + 2]; }
   __device__ __forceinline__ double w(int u) const { return r[4 * u + 3]; }
 };
+// one s_waitcnt for a group of batches: names every destination "+s" so no consumer is scheduled above it
+template <typename T, int G>
+__device__ __forceinline__ void sgpr_wait(SgprBatch<T> (&b)[G]) {
+  if constexpr (G == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b[0].r));
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(b[0].r), "+s"(b[1].r));
+}
+
 enum : int { MATH_SCALAR = 0, MATH_PACKED = 1 };
 // What a workgroup does with its accelerations:
 //   EPI_SLAB  write them to its split's slab (the separate integrate_kernel, or nbx_accel, consumes the slabs)
@@ -293,30 +300,43 @@ __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> 
     // "+s"; SMEM returns out of order, hence lgkmcnt(0)).  The final trip over-reads one batch past
     // the split; the array carries kSgprOverread spare records for the last split.
     constexpr int U = kSgprBatch<T>;
+    // G batches travel together.  SMEM returns out of order, so only lgkmcnt(0) is a usable wait: the cover a
+    // request gets is the arithmetic of ONE group.  The wave-split kernel runs 8 waves per SIMD and needs <= 80 SGPRs
+    // (G = 1); the plain SGPR kernel serves the reference-order shapes, which run 1-2 waves per SIMD when a rank owns
+    // few bodies and need the longer cover of G = 2 (8 j records, 64 SGPRs of payload).
+    constexpr int G = WSPLIT ? 1 : 2;
     const char* p = reinterpret_cast<const char*>(a.posm + j0);
     if (j0 < j1) {
-      SgprBatch<T> ba;
-      ba.load_first(p);
-      ba.wait();
-      // Invariant at the loop head AND at the back edge: `ba` has landed.  No asm-loaded value is
-      // in flight across the back edge, so a register copy the compiler may insert for the loop-carried
-      // value can never read (or be overtaken by) a pending scalar load.  tests/test_isa_audit.py checks
-      // the compiled code: nothing touches a batch's SGPRs between its s_load and its s_waitcnt.
-      for (int j = j0; j < j1; j += 2 * U) {
-        SgprBatch<T> bb;
-        bb.load(p + 64);
-        __builtin_amdgcn_sched_barrier(0);  // keep the arithmetic below the request (no operand ties it)
+      SgprBatch<T> ba[G];
+      ba[0].load_first(p);
 #pragma unroll
-        for (int u = 0; u < U; ++u) ib.apply(ba.x(u), ba.y(u), ba.z(u), ba.w(u));
+      for (int g = 1; g < G; ++g) ba[g].load(p + 64 * g);
+      sgpr_wait<T, G>(ba);
+      // Invariant at the loop head AND at the back edge: group `ba` has landed.  No asm-loaded value is in flight
+      // across the back edge, so a register copy the compiler may insert for the loop-carried value can never read
+      // (or be overtaken by) a pending scalar load.  tests/test_isa_audit.py checks the compiled code: nothing touches
+      // a batch's SGPRs between its s_load and the next s_waitcnt lgkmcnt(0).
+      for (int j = j0; j < j1; j += 2 * G * U) {
+        SgprBatch<T> bb[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) bb[g].load(p + 64 * (G + g));
+        __builtin_amdgcn_sched_barrier(0);  // keep the arithmetic below the requests (no operand ties it)
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int u = 0; u < U; ++u) ib.apply(ba[g].x(u), ba[g].y(u), ba[g].z(u), ba[g].w(u));
         __builtin_amdgcn_sched_barrier(0);
-        bb.wait();
-        ba.load(p + 128);  // next trip's first batch; over-reads 64 B past the split on the last trip
+        sgpr_wait<T, G>(bb);
+#pragma unroll
+        for (int g = 0; g < G; ++g) ba[g].load(p + 64 * (2 * G + g));  // next trip's first group (over-read on the last trip)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) ib.apply(bb.x(u), bb.y(u), bb.z(u), bb.w(u));
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int u = 0; u < U; ++u) ib.apply(bb[g].x(u), bb[g].y(u), bb[g].z(u), bb[g].w(u));
         __builtin_amdgcn_sched_barrier(0);
-        ba.wait();
-        p += 128;
+        sgpr_wait<T, G>(ba);
+        p += 128 * G;
       }
     }
   }

@@ -43,14 +43,18 @@ def _sregs(operand_text):
 
 def test_every_force_kernel_instance_is_present(kernels):
     names = [k for k in kernels if "force_kernel" in k]
-    assert len(names) >= 40, len(names)
+    assert len(names) >= 36, len(names)
     assert any("integrate_kernel" in k for k in kernels) and any("ke_reduce_kernel" in k for k in kernels)
 
 
 def test_no_scratch_no_spills(kernels):
-    for name, (_, desc) in kernels.items():
+    for name, (body, desc) in kernels.items():
         m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", desc)
         assert m and int(m.group(1)) == 0, name
+        # SGPR spills go to VGPR lanes (v_writelane / v_readlane): forbidden in the force kernels, where a spill placed
+        # between an asm s_load and its wait would copy registers whose data has not landed yet
+        if "force_kernel" in name:
+            assert "v_writelane_b32" not in body and "v_readlane_b32" not in body, name
 
 
 def test_asm_scalar_loads_are_never_touched_before_their_wait(kernels):
