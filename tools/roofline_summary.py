@@ -18,12 +18,20 @@ import shutil
 import sys
 
 
+def dominant_kernel(path, match):
+    """A run may launch several instances of the kernel template (e.g. bench.py's parity probe uses the default
+    shape): keep the instance with the most dispatches."""
+    names = collections.Counter(r["Kernel_Name"] for r in csv.DictReader(open(path)) if match in r["Kernel_Name"])
+    return names.most_common(1)[0][0] if names else match
+
+
 def per_kernel(path, match):
+    match = dominant_kernel(path, match)
     acc = collections.defaultdict(list)
     dur = []
     meta = {}
     for r in csv.DictReader(open(path)):
-        if match not in r["Kernel_Name"]:
+        if match != r["Kernel_Name"]:
             continue
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -71,7 +79,8 @@ def main():
     read_bytes = None if fetch_kib is None else 2.0 * fetch_kib * 1024.0
     write_bytes = None if write_kib is None else write_kib * 1024.0
     traffic = None if (read_bytes is None or write_bytes is None) else read_bytes + write_bytes
-    force_row = next((r for r in rows if match in r["Name"]), None)
+    force_rows = sorted((r for r in rows if match in r["Name"]), key=lambda r: -int(r["Calls"]))
+    force_row = force_rows[0] if force_rows else None
     avg_ms = float(force_row["AverageNs"]) / 1e6 if force_row else None
     clock_ghz = None
     if "GRBM_GUI_ACTIVE" in counters and durs.get("pmc_grbm"):
