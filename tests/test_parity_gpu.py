@@ -835,3 +835,44 @@ def test_config3_size_reference_order_vs_reference_arithmetic(nbx):
     tr, _ = _side_by_side(nbx, 1048576, 6, chunk=6)
     assert rel_err(tr["reference_order"], tr["exact"]).max() < 1e-5      # measured 5e-7 over 100 steps
     assert rel_err(tr["tree"], tr["exact"]).max() > 2e-4                  # measured 8.5e-4 from step 1 on
+
+
+@pytest.mark.parametrize("prec", [32, 64])
+def test_reference_order_is_partition_independent_bit_for_bit(nbx, prec):
+    """One accumulator per body over all j in ascending order: the result for a body cannot depend on who owns it, on the
+    j source, on bodies per lane or on graph replay -- single context, 3 logical ranks and every plain shape agree bitwise."""
+    n, steps = 5001, 12
+    ic = nbx.initial_conditions(n, prec)
+    with nbx.Context(n, prec, summation_order=nbx.ORDER_REFERENCE) as c:
+        c.upload(ic)
+        st = c.stats()
+        assert st["summation_order"] == nbx.ORDER_REFERENCE and st["j_split"] == 1 and st["fused_epilogue"] == 1
+        ke = c.step(steps)
+        ref = c.download()
+    for opts in (dict(kernel_variant=nbx.KERNEL_LDS, bodies_per_lane=1), dict(kernel_variant=nbx.KERNEL_SGPR, bodies_per_lane=4),
+                 dict(kernel_variant=nbx.KERNEL_LDS, bodies_per_lane=4, fused_epilogue=2), dict(use_graph=1)):
+        with nbx.Context(n, prec, summation_order=nbx.ORDER_REFERENCE, **opts) as c:
+            c.upload(ic)
+            c.step(steps, kenergy=False)
+            d = c.download()
+        for f in ref:
+            assert np.array_equal(d[f], ref[f]), (opts, f)
+    with nbx.Group(n, prec, n_ranks=3, devices=[0, 0, 0], summation_order=nbx.ORDER_REFERENCE) as g:
+        g.upload(ic)
+        keg = g.step(steps)
+        dg = g.download()
+        assert g.info(1)[2]["summation_order"] == nbx.ORDER_REFERENCE
+    for f in ref:
+        assert np.array_equal(dg[f], ref[f]), f
+    assert abs(keg / ke - 1.0) < 1e-13
+
+
+def test_auto_order_threshold(nbx):
+    for n, want in ((131071, nbx.ORDER_TREE), (131072, nbx.ORDER_REFERENCE)):
+        with nbx.Context(n) as c:
+            assert c.stats()["summation_order"] == want, n
+    with nbx.Context(1048576, i_begin=0, i_count=131072, n_alloc=1048576) as c:      # one rank of the 8-GPU configuration
+        st = c.stats()
+        assert st["summation_order"] == nbx.ORDER_REFERENCE and st["j_split"] == 1 and st["bodies_per_lane"] == 2
+    with nbx.Context(262144, j_split=8) as c:                                        # an explicit split means tree
+        assert c.stats()["summation_order"] == nbx.ORDER_TREE
