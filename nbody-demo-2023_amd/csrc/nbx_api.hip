@@ -160,7 +160,8 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   if (order != NBX_ORDER_REFERENCE && order != NBX_ORDER_TREE) {
     const bool shape_given = o.j_split > 0 || variant == NBX_KERNEL_SGPRW;
     if (o.j_split == 1 && variant != NBX_KERNEL_SGPRW) order = NBX_ORDER_REFERENCE;
-    else order = (!shape_given && c->i_count >= 131072) ? NBX_ORDER_REFERENCE : NBX_ORDER_TREE;
+    // fp64 keeps the tree: its summation noise (~1e-13) is far below the 1e-10 fp64 gate in either order
+    else order = (!shape_given && c->precision == 32 && c->i_count >= 131072) ? NBX_ORDER_REFERENCE : NBX_ORDER_TREE;
   }
   c->order = order;
   if (order == NBX_ORDER_REFERENCE) {

@@ -876,3 +876,5 @@ def test_auto_order_threshold(nbx):
         assert st["summation_order"] == nbx.ORDER_REFERENCE and st["j_split"] == 1 and st["bodies_per_lane"] == 2
     with nbx.Context(262144, j_split=8) as c:                                        # an explicit split means tree
         assert c.stats()["summation_order"] == nbx.ORDER_TREE
+    with nbx.Context(262144, 64) as c:                                               # fp64: noise 1e-13, tree is fine
+        assert c.stats()["summation_order"] == nbx.ORDER_TREE
