@@ -13,7 +13,6 @@ PyTorch is plumbing here: rendezvous, the collective, barriers.  The compute is 
 """
 import ctypes
 
-import numpy as np
 
 BLOCK_ALIGN = 256  # = the kernels' j tile: keeps every rank's block a whole number of tiles
 

@@ -1,5 +1,5 @@
 """Throughput of reference-order shapes (j_split = 1) by owned-body count, bodies/lane and j source."""
-import sys, time
+import sys
 sys.path.insert(0, 'nbody-demo-2023_amd')
 import nbx
 cases = [(131072, 131072), (262144, 262144), (524288, 524288), (1048576, 1048576), (1048576, 131072), (1048576, 262144)]
