@@ -2,9 +2,10 @@
 //
 // The per-time-step work of the reference's GSimulation::start()
 // (ver7/GSimulation.cpp:138-200):
-//   force_kernel      all-pairs softened-gravity acceleration   (ver7:141-177)
-//   integrate_kernel  v += a*dt; x += v*dt; m*v^2 partial sums  (ver7:178-198)
-//   ke_reduce_kernel  ordered final sum of the partials         (ver7:179,200)
+//   force_kernel        all-pairs softened-gravity acceleration   (ver7:141-177)
+//   integrate_kernel    v += a*dt; x += v*dt; m*v^2 partial sums  (ver7:178-198)
+//   ke_reduce_kernel    ordered final sum of the partials         (ver7:179,200)
+//   force_exact_kernel  validation: the reference build's arithmetic, bit for bit
 //
 // Data layout in HBM (all resident for the lifetime of a context):
 //   posm[2][n_alloc]  {x, y, z, G*m}   one 16 B (fp32) / 32 B (fp64) record per body, double
@@ -19,9 +20,14 @@
 // in registers (register blocking: one j record feeds B independent 13-instruction chains, which
 // hides the v_rsq_f32 latency and amortises the j fetch).  The j records come either from an LDS
 // tile (256 records, double buffered, every lane reads the same address => broadcast
-// ds_read_b128, no bank conflicts) or from wave-uniform scalar loads (s_load_dwordx4..16 into
-// SGPRs: costs neither LDS bandwidth nor VGPRs).  No MFMA: the pair kernel is rsqrt/FMA-chain
-// bound and its contraction forms cancel catastrophically in fp32.
+// ds_read_b128, no bank conflicts) or from wave-uniform scalar loads (hand-pipelined
+// s_load_dwordx16 into SGPRs: costs neither LDS bandwidth nor VGPRs).  No MFMA: the pair kernel is
+// rsqrt/FMA-chain bound and its contraction forms cancel catastrophically in fp32.
+//
+// Two summation orders (include/nbx.h): REFERENCE = one accumulator per body over all
+// j ascending (grid.y = 1; reproduces the reference's rounding noise, which is what parity means at
+// n >= 262144), TREE = the four waves of a workgroup and grid.y workgroups each sum a j sub-range and
+// the partials are added in fixed order (fastest, closest to an fp64 sum).
 #pragma once
 #include <hip/hip_runtime.h>
 
