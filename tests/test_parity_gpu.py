@@ -878,3 +878,50 @@ def test_auto_order_threshold(nbx):
         assert c.stats()["summation_order"] == nbx.ORDER_TREE
     with nbx.Context(262144, 64) as c:                                               # fp64: noise 1e-13, tree is fine
         assert c.stats()["summation_order"] == nbx.ORDER_TREE
+
+
+def test_randomized_shapes_orders_and_sizes_against_exact_mode(nbx):
+    """80 pseudo-random (n, precision, kernel, bodies/lane, j-split, order, epilogue, slice) combinations, fixed seed: every one
+    must agree with the bit-exact reference arithmetic on the accelerations (2e-5 of |a|inf) and on a 3-step state."""
+    rng = np.random.default_rng(20261004)
+    tried = 0
+    for _ in range(80):
+        n = int(rng.choice([1, 2, 7, 63, 64, 65, 255, 256, 257, 511, 1000, 1023, 1025, 2047, 3000, 4099, 6001]))
+        prec = int(rng.choice([32, 32, 32, 64]))
+        opts = dict(kernel_variant=int(rng.choice([0, 1, 2, 3])), bodies_per_lane=int(rng.choice([0, 1, 2, 4, 8])),
+                    j_split=int(rng.choice([0, 0, 1, 2, 3, 5, 16, 64])), summation_order=int(rng.choice([0, 1, 2])),
+                    fused_epilogue=int(rng.choice([0, 1, 2])), use_graph=int(rng.choice([0, 1, 2])))
+        sl = {}
+        if n > 300 and rng.random() < 0.3:      # a slice of a larger padded array, as one rank of a sharded run has
+            ib = int(rng.integers(0, n // 2))
+            sl = dict(i_begin=ib, i_count=int(rng.integers(1, n - ib + 1)), n_alloc=int(-(-n // 256) * 256 + 256 * rng.integers(0, 3)))
+        ic = nbx.initial_conditions(n, prec)
+        try:
+            c = nbx.Context(n, prec, **opts, **sl)
+        except nbx.NbxError as e:
+            assert e.code == nbx.NBX_ERR_ARG, (opts, sl, str(e))
+            continue
+        with c, nbx.Context(n, prec, kernel_variant=nbx.KERNEL_EXACT, **sl) as x:
+            c.upload(ic)
+            x.upload(ic)
+            a, b = c.accel(), x.accel()
+            st = c.stats()
+            lo, hi = st["i_begin"], st["i_begin"] + st["i_count"]
+            scale = max(max(float(np.abs(v[lo:hi]).max()) for v in b), 1e-300)   # float(): a float32 zero would swallow 1e-300
+            err = max(float(np.abs(u[lo:hi].astype(np.float64) - v[lo:hi]).max()) for u, v in zip(a, b)) / scale
+            assert err < (2e-5 if prec == 32 else 1e-12), (n, prec, opts, sl, err)
+            if not sl:
+                k1, k2 = c.step(3), x.step(3)
+                assert abs(k1 - k2) <= 2e-5 * abs(k2) + 1e-300, (n, prec, opts, k1, k2)
+                d1, d2 = c.download(), x.download()
+                for f in d1:
+                    assert np.allclose(d1[f], d2[f], rtol=1e-4 if prec == 32 else 1e-11, atol=1e-6 if prec == 32 else 1e-14), (n, opts, f)
+            else:
+                c.step_local()
+                c.commit()
+                x.step_local()
+                x.commit()
+                p1, p2 = c.kenergy_partial(), x.kenergy_partial()
+                assert abs(p1 - p2) <= 2e-5 * abs(p2) + 1e-300, (n, prec, opts, sl)
+        tried += 1
+    assert tried >= 60
