@@ -185,7 +185,7 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   if (B == 0) B = c->i_count >= 16384 ? 4 : 2;
   const int iblk = (variant == NBX_KERNEL_SGPRW ? 64 : kBlock) * B;  // bodies per workgroup
   // j-range granularity of one split: a whole LDS tile / two pipelined SGPR batches (per wave)
-  const int gran = variant == NBX_KERNEL_LDS ? kTile : (variant == NBX_KERNEL_SGPRW ? 32 : 32);
+  const int gran = variant == NBX_KERNEL_LDS ? kTile : 32;
   const int max_split = std::max(1, c->n_alloc / gran);
   int S = o.j_split;
   if (S <= 0) {
@@ -450,7 +450,6 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
   c->rec = precision == 32 ? sizeof(float4) : sizeof(double4);
   c->i_begin = o.i_begin;
   c->i_count = o.i_count == 0 ? n - o.i_begin : o.i_count;
-  if (o.i_count == 0 && o.i_begin != 0) c->i_count = n - o.i_begin;
   c->n_alloc = round_up(std::max(n, o.n_alloc), kTile);
   c->own_pad = round_up(c->i_count, kBlock);
 

@@ -27,6 +27,17 @@ int env_int(const char* name, int dflt) {
   return (v && *v) ? std::atoi(v) : dflt;
 }
 
+const char* kernel_name(int variant) {
+  switch (variant) {
+    case NBX_KERNEL_LDS: return "lds";
+    case NBX_KERNEL_SGPR: return "sgpr";
+    case NBX_KERNEL_SGPRW: return "sgprw";
+    case NBX_KERNEL_EXACT: return "exact";
+    case NBX_KERNEL_EXACT_FMA: return "exact-fma";
+  }
+  return "?";
+}
+
 void die_nbx(const char* where) {
   std::cerr << "nbody.x: " << where << " failed: " << nbx_last_error() << std::endl;
   std::exit(1);
@@ -258,7 +269,7 @@ void GSimulation::start() {
   std::cout << "===============================" << std::endl;
   // extra lines AFTER the reference's footer, so line-wise diffs of the reference part still match
   std::cout << "# Device             : " << st.device_name << " (" << st.cu_count << " CUs), fp" << st.precision
-            << ", kernel " << (st.kernel_variant == NBX_KERNEL_LDS ? "lds" : st.kernel_variant == NBX_KERNEL_SGPR ? "sgpr" : st.kernel_variant == NBX_KERNEL_EXACT ? "exact" : "sgprw")
+            << ", kernel " << kernel_name(st.kernel_variant)
             << ", " << (st.summation_order == NBX_ORDER_REFERENCE ? "reference-order" : "tree") << " sums"
             << ", bodies/lane " << st.bodies_per_lane << ", j-split " << st.j_split << ", grid " << st.force_grid_x << "x"
             << st.force_grid_y << std::endl;
@@ -274,7 +285,7 @@ void GSimulation::start() {
                    "\"pair_per_s_total\": %.9g, \"gflops_avg_reference_convention\": %.9g, \"kenergy_last_printed\": %.9g, "
                    "\"kernel\": \"%s\", \"bodies_per_lane\": %d, \"j_split\": %d, \"grid\": [%d, %d], \"device\": \"%s\"}\n",
                    n, nsteps, st.precision, (int)ranks, ranks > 1 ? (rccl ? "rccl" : "copy") : "none", _totTime, pps, av,
-                   (double)_kenergy, st.kernel_variant == NBX_KERNEL_LDS ? "lds" : st.kernel_variant == NBX_KERNEL_SGPR ? "sgpr" : "sgprw",
+                   (double)_kenergy, kernel_name(st.kernel_variant),
                    st.bodies_per_lane, st.j_split, st.force_grid_x, st.force_grid_y, st.device_name);
       std::fclose(jf);
     }
