@@ -87,9 +87,10 @@ typedef struct nbx_opts {
                                   (n=1048576 x 100); needs j_split = 1, so parallelism = owned bodies
                               2 = NBX_ORDER_TREE: partial sums per wave and per j-split, added in fixed order: fastest and
                                   ~40x closer to an fp64 sum, but NOT the reference's rounding
-                              0 = auto: REFERENCE when an fp32 context owns >= 131072 bodies (enough to fill the GPU), TREE
-                                  below (there the two agree with the reference within the 1e-4 gate) and for fp64 (its
-                                  summation noise is ~1e-13, far inside the 1e-10 gate either way) */
+                              0 = auto: REFERENCE for fp32 runs of n > 131072 bodies (the noise grows with the length of the
+                                  sum, whatever slice of the bodies this context owns), TREE up to there (the two agree
+                                  with the reference within the 1e-4 gate: 2e-5 over 500 steps at n = 131072) and for fp64
+                                  (its summation noise is ~1e-13, far inside the 1e-10 gate either way) */
   int32_t reserved[3];
 } nbx_opts;
 

@@ -38,6 +38,9 @@ int fail(int code, const std::string& msg) {
   } while (0)
 
 constexpr int kMaxProfiledLaunches = 8192;
+// NBX_ORDER_AUTO: fp32 sums of more terms than this use the reference's order.  131072 x 500 steps agrees with the
+// reference to 2e-5 in tree order (profiles/r01_validate_orders_n131072_s500.log); 262144 x 200 does not (1.3e-3).
+constexpr int kTreeOrderMaxN = 131072;
 
 }  // namespace
 
@@ -153,15 +156,17 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
     return;
   }
   // Summation order (include/nbx.h).  The reference adds a body's n terms one after the other into one fp32
-  // accumulator; at n >= 262144 that sum carries ~1e-5 of rounding noise per step which heats the system (kenergy
-  // +5e-4..1e-3 against an fp64 run).  A tree of partial sums does not reproduce that, a single accumulator per body
-  // in the same j order does (to 5e-5 / 5e-7, tools/validate_big.py) -- at the price of one chain per owned body.
+  // accumulator; from n = 262144 that sum carries ~1e-5 of rounding noise per step which heats the system (kenergy
+  // +5e-4..1e-3 against an fp64 run; 1.6e-5 over 500 steps at n = 131072).  A tree of partial sums does not reproduce
+  // that, a single accumulator per body in the same j order does (to 5e-5 / 5e-7, tools/validate_big.py) -- at the
+  // price of one chain per owned body.  The noise is a property of the LENGTH of the sum, i.e. of n, not of how many
+  // bodies this context owns: every rank of a sharded run takes the same decision.
   int order = o.summation_order;
   if (order != NBX_ORDER_REFERENCE && order != NBX_ORDER_TREE) {
     const bool shape_given = o.j_split > 0 || variant == NBX_KERNEL_SGPRW;
     if (o.j_split == 1 && variant != NBX_KERNEL_SGPRW) order = NBX_ORDER_REFERENCE;
     // fp64 keeps the tree: its summation noise (~1e-13) is far below the 1e-10 fp64 gate in either order
-    else order = (!shape_given && c->precision == 32 && c->i_count >= 131072) ? NBX_ORDER_REFERENCE : NBX_ORDER_TREE;
+    else order = (!shape_given && c->precision == 32 && c->n > kTreeOrderMaxN) ? NBX_ORDER_REFERENCE : NBX_ORDER_TREE;
   }
   c->order = order;
   if (order == NBX_ORDER_REFERENCE) {
@@ -170,7 +175,8 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
     const int maxBr = c->precision == 32 ? 8 : 4;
     if (B != 1 && B != 2 && B != 4 && B != 8) B = 0;
     if (B > maxBr) B = maxBr;
-    if (B == 0) B = c->i_count >= 393216 ? 4 : 2;  // measured: tools/seq_shapes.py
+    // measured (profiles/r01_reference_order_shapes.txt): the chains are the owned bodies, so few bodies want few per lane
+    if (B == 0) B = c->i_count >= 393216 ? 4 : (c->i_count >= 98304 ? 2 : 1);
     c->B = B; c->S = 1; c->jps = c->n_alloc; c->variant = variant;
     c->math = (c->precision == 32 && B >= 2) ? MATH_PACKED : MATH_SCALAR;
     c->epi = o.fused_epilogue == 2 ? EPI_SLAB : EPI_ROW;

@@ -868,9 +868,15 @@ def test_reference_order_is_partition_independent_bit_for_bit(nbx, prec):
 
 
 def test_auto_order_threshold(nbx):
-    for n, want in ((131071, nbx.ORDER_TREE), (131072, nbx.ORDER_REFERENCE)):
+    for n, want in ((131072, nbx.ORDER_TREE), (131073, nbx.ORDER_REFERENCE), (262144, nbx.ORDER_REFERENCE)):
         with nbx.Context(n) as c:
             assert c.stats()["summation_order"] == want, n
+    # the decision follows n, the length of the sums, not the slice a rank owns: every rank of a sharded run agrees
+    with nbx.Context(262144, i_begin=65536, i_count=32768, n_alloc=262144) as c:
+        st = c.stats()
+        assert st["summation_order"] == nbx.ORDER_REFERENCE and st["j_split"] == 1 and st["bodies_per_lane"] == 1
+    with nbx.Context(131072, i_begin=0, i_count=16384, n_alloc=131072) as c:
+        assert c.stats()["summation_order"] == nbx.ORDER_TREE
     with nbx.Context(1048576, i_begin=0, i_count=131072, n_alloc=1048576) as c:      # one rank of the 8-GPU configuration
         st = c.stats()
         assert st["summation_order"] == nbx.ORDER_REFERENCE and st["j_split"] == 1 and st["bodies_per_lane"] == 2
