@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -36,6 +37,20 @@ int fail(int code, const std::string& msg) {
     if (e_ != hipSuccess)                                                                      \
       return fail(NBX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));          \
   } while (0)
+
+// No C++ exception may cross the C boundary: every entry point that can allocate host memory runs inside this.
+template <typename F>
+int guarded(const char* where, F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    try { return fail(NBX_ERR_ALLOC, std::string(where) + ": out of host memory"); } catch (...) { return NBX_ERR_ALLOC; }
+  } catch (const std::exception& e) {
+    try { return fail(NBX_ERR_STATE, std::string(where) + ": " + e.what()); } catch (...) { return NBX_ERR_STATE; }
+  } catch (...) {
+    return NBX_ERR_STATE;
+  }
+}
 
 constexpr int kMaxProfiledLaunches = 8192;
 // NBX_ORDER_AUTO: fp32 sums of more terms than this use the reference's order.  131072 x 500 steps agrees with the
@@ -423,6 +438,7 @@ const char* nbx_last_error(void) { return g_err.c_str(); }
 int32_t nbx_abi_version(void) { return NBX_ABI_VERSION; }
 
 int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts) {
+  return guarded("nbx_create", [&]() -> int {
   if (!out) return fail(NBX_ERR_ARG, "nbx_create: out is NULL");
   *out = nullptr;
   if (n <= 0) return fail(NBX_ERR_ARG, "nbx_create: n must be > 0");
@@ -450,6 +466,7 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
 
   nbx_ctx* c = new (std::nothrow) nbx_ctx();
   if (!c) return fail(NBX_ERR_ALLOC, "nbx_create: out of host memory");
+  struct Owner { nbx_ctx* c; ~Owner() { nbx_destroy(c); } } owner{c};  // every failure path below frees the context
   c->device = dev;
   c->n = n;
   c->precision = precision;
@@ -464,7 +481,6 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
     hipError_t e_ = (expr);                                                              \
     if (e_ != hipSuccess) {                                                              \
       std::string m_ = std::string("nbx_create: " #expr ": ") + hipGetErrorString(e_);   \
-      nbx_destroy(c);                                                                    \
       return fail(e_ == hipErrorOutOfMemory ? NBX_ERR_ALLOC : NBX_ERR_DEVICE, m_);       \
     }                                                                                    \
   } while (0)
@@ -501,14 +517,12 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
   CREATE_TRY(hipMemsetAsync(c->ke_part, 0, sizeof(double) * (size_t)max_parts, c->stream));
   CREATE_TRY(hipStreamSynchronize(c->stream));
 #undef CREATE_TRY
-  if (ensure_ke_cap(c, 64) != NBX_OK) {
-    std::string m = g_err;
-    nbx_destroy(c);
-    return fail(NBX_ERR_ALLOC, m);
-  }
+  if (ensure_ke_cap(c, 64) != NBX_OK) return NBX_ERR_ALLOC;  // message set by ensure_ke_cap
+  owner.c = nullptr;
   *out = c;
   g_err.clear();
   return NBX_OK;
+  });
 }
 
 void nbx_destroy(nbx_ctx* c) {
@@ -531,6 +545,7 @@ void nbx_destroy(nbx_ctx* c) {
 
 int nbx_upload(nbx_ctx* c, const void* px, const void* py, const void* pz, const void* vx, const void* vy,
                const void* vz, const void* m) {
+  return guarded("nbx_upload", [&]() -> int {
   if (!c) return fail(NBX_ERR_ARG, "nbx_upload: ctx is NULL");
   if (!px || !py || !pz || !vx || !vy || !vz || !m) return fail(NBX_ERR_ARG, "nbx_upload: NULL array");
   int rc = use_device(c);
@@ -547,9 +562,11 @@ int nbx_upload(nbx_ctx* c, const void* px, const void* py, const void* pz, const
   c->uploaded = true;
   c->pending_commit = false;
   return NBX_OK;
+  });
 }
 
 static int step_common(nbx_ctx* c, double dt, int32_t nsteps, double* ke_last, double* ke_trace) {
+  return guarded("nbx_step", [&]() -> int {
   if (!c) return fail(NBX_ERR_ARG, "nbx_step: ctx is NULL");
   if (nsteps < 0) return fail(NBX_ERR_ARG, "nbx_step: nsteps < 0");
   if (!c->uploaded) return fail(NBX_ERR_STATE, "nbx_step: nbx_upload has not been called");
@@ -611,6 +628,7 @@ static int step_common(nbx_ctx* c, double dt, int32_t nsteps, double* ke_last, d
     }
   }
   return NBX_OK;
+  });
 }
 
 int nbx_step(nbx_ctx* c, double dt, int32_t nsteps, double* kenergy_out) {
@@ -623,6 +641,7 @@ int nbx_step_trace(nbx_ctx* c, double dt, int32_t nsteps, double* ke_trace) {
 }
 
 int nbx_step_local(nbx_ctx* c, double dt) {
+  return guarded("nbx_step_local", [&]() -> int {
   if (!c) return fail(NBX_ERR_ARG, "nbx_step_local: ctx is NULL");
   if (!c->uploaded) return fail(NBX_ERR_STATE, "nbx_step_local: nbx_upload has not been called");
   if (c->pending_commit) return fail(NBX_ERR_STATE, "nbx_step_local: previous step not committed");
@@ -632,6 +651,7 @@ int nbx_step_local(nbx_ctx* c, double dt) {
   if (rc) return rc;
   c->pending_commit = true;
   return NBX_OK;
+  });
 }
 
 int nbx_exchange_buffer(nbx_ctx* c, void** dev_ptr, size_t* total_bytes, size_t* own_offset_bytes, size_t* own_bytes) {
@@ -654,6 +674,7 @@ int nbx_commit(nbx_ctx* c) {
 }
 
 int nbx_kenergy_partial(nbx_ctx* c, double* sum_mv2) {
+  return guarded("nbx_kenergy_partial", [&]() -> int {
   if (!c || !sum_mv2) return fail(NBX_ERR_ARG, "nbx_kenergy_partial: NULL argument");
   int rc = use_device(c);
   if (rc) return rc;
@@ -666,9 +687,11 @@ int nbx_kenergy_partial(nbx_ctx* c, double* sum_mv2) {
   HIP_TRY(hipMemcpyAsync(sum_mv2, c->ke_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return NBX_OK;
+  });
 }
 
 int nbx_accel(nbx_ctx* c, void* ax, void* ay, void* az) {
+  return guarded("nbx_accel", [&]() -> int {
   if (!c) return fail(NBX_ERR_ARG, "nbx_accel: ctx is NULL");
   if (!c->uploaded) return fail(NBX_ERR_STATE, "nbx_accel: nbx_upload has not been called");
   if (c->pending_commit) return fail(NBX_ERR_STATE, "nbx_accel: a local step awaits nbx_commit");
@@ -676,6 +699,7 @@ int nbx_accel(nbx_ctx* c, void* ax, void* ay, void* az) {
   if (rc) return rc;
   return c->precision == 32 ? accel_t<float>(c, (float*)ax, (float*)ay, (float*)az)
                             : accel_t<double>(c, (double*)ax, (double*)ay, (double*)az);
+  });
 }
 
 int nbx_sync(nbx_ctx* c) {
@@ -687,6 +711,7 @@ int nbx_sync(nbx_ctx* c) {
 }
 
 int nbx_download(nbx_ctx* c, void* px, void* py, void* pz, void* vx, void* vy, void* vz) {
+  return guarded("nbx_download", [&]() -> int {
   if (!c) return fail(NBX_ERR_ARG, "nbx_download: ctx is NULL");
   if (!c->uploaded) return fail(NBX_ERR_STATE, "nbx_download: nbx_upload has not been called");
   int rc = use_device(c);
@@ -694,9 +719,11 @@ int nbx_download(nbx_ctx* c, void* px, void* py, void* pz, void* vx, void* vy, v
   return c->precision == 32
              ? download_t<float>(c, (float*)px, (float*)py, (float*)pz, (float*)vx, (float*)vy, (float*)vz)
              : download_t<double>(c, (double*)px, (double*)py, (double*)pz, (double*)vx, (double*)vy, (double*)vz);
+  });
 }
 
 int nbx_profile(nbx_ctx* c, int32_t enable) {
+  return guarded("nbx_profile", [&]() -> int {
   if (!c) return fail(NBX_ERR_ARG, "nbx_profile: ctx is NULL");
   int rc = use_device(c);
   if (rc) return rc;
@@ -717,9 +744,11 @@ int nbx_profile(nbx_ctx* c, int32_t enable) {
   }
   c->profiling = enable != 0;
   return NBX_OK;
+  });
 }
 
 int nbx_stats(nbx_ctx* c, nbx_stats_t* s) {
+  return guarded("nbx_stats", [&]() -> int {
   if (!c || !s) return fail(NBX_ERR_ARG, "nbx_stats: NULL argument");
   int rc = use_device(c);
   if (rc) return rc;
@@ -744,6 +773,7 @@ int nbx_stats(nbx_ctx* c, nbx_stats_t* s) {
   std::snprintf(s->device_name, sizeof(s->device_name), "%s%s%s", c->prop.name, c->prop.name[0] ? " " : "",
                 c->prop.gcnArchName);
   return NBX_OK;
+  });
 }
 
 }  // extern "C"
@@ -841,6 +871,7 @@ extern "C" {
 
 int nbx_group_create(nbx_group** out, int32_t n, int32_t precision, int32_t n_ranks, const int32_t* devices,
                      const nbx_opts* opts) {
+  return guarded("nbx_group_create", [&]() -> int {
   if (!out) return fail(NBX_ERR_ARG, "nbx_group_create: out is NULL");
   *out = nullptr;
   if (n <= 0) return fail(NBX_ERR_ARG, "nbx_group_create: n must be > 0");
@@ -857,21 +888,20 @@ int nbx_group_create(nbx_group** out, int32_t n, int32_t precision, int32_t n_ra
   }
   nbx_group* g = new (std::nothrow) nbx_group();
   if (!g) return fail(NBX_ERR_ALLOC, "nbx_group_create: out of host memory");
+  struct Owner { nbx_group* g; ~Owner() { nbx_group_destroy(g); } } owner{g};  // every failure path below frees the group
   g->n = n; g->precision = precision; g->P = P; g->block = block; g->n_alloc = P * block;
   bool distinct = true;
   for (int r = 0; r < P; ++r) {
     const int d = devices ? devices[r] : r % ndev;
-    if (d < 0 || d >= ndev) { nbx_group_destroy(g); return fail(NBX_ERR_ARG, "nbx_group_create: device ordinal out of range"); }
+    if (d < 0 || d >= ndev) return fail(NBX_ERR_ARG, "nbx_group_create: device ordinal out of range");
     for (int q : g->dev) distinct = distinct && q != d;
     g->dev.push_back(d);
   }
   nbx_opts o;
   std::memset(&o, 0, sizeof(o));
   if (opts) {
-    if (opts->struct_size != 0 && opts->struct_size != (int32_t)sizeof(nbx_opts)) {
-      nbx_group_destroy(g);
+    if (opts->struct_size != 0 && opts->struct_size != (int32_t)sizeof(nbx_opts))
       return fail(NBX_ERR_ARG, "nbx_group_create: nbx_opts.struct_size does not match this library");
-    }
     o = *opts;
   }
   o.stream = nullptr; o.external_stream = 0; o.use_graph = 2;  // every rank: own stream, plain launches
@@ -882,7 +912,7 @@ int nbx_group_create(nbx_group** out, int32_t n, int32_t precision, int32_t n_ra
     o.n_alloc = g->n_alloc;
     nbx_ctx* c = nullptr;
     const int rc = nbx_create(&c, n, precision, &o);
-    if (rc != NBX_OK) { const std::string m = g_err; nbx_group_destroy(g); return fail(rc, "nbx_group_create: rank " + std::to_string(r) + ": " + m); }
+    if (rc != NBX_OK) { const std::string m = g_err; return fail(rc, "nbx_group_create: rank " + std::to_string(r) + ": " + m); }
     g->rank.push_back(c);
   }
   const char* force = std::getenv("NBX_EXCHANGE");  // "copy" forces the peer-copy path, "rccl" insists on RCCL
@@ -894,24 +924,22 @@ int nbx_group_create(nbx_group** out, int32_t n, int32_t precision, int32_t n_ra
     if (e == 0) g->use_rccl = true;
     else g->comm.clear();
   }
-  if (insist && !g->use_rccl) {
-    nbx_group_destroy(g);
+  if (insist && !g->use_rccl)
     return fail(NBX_ERR_DEVICE, "nbx_group_create: NBX_EXCHANGE=rccl but RCCL is unavailable for these devices");
-  }
   if (!g->use_rccl) {
     g->done.assign(P, nullptr);
     for (int r = 0; r < P; ++r) {
-      if (hipSetDevice(g->dev[r]) != hipSuccess || hipEventCreateWithFlags(&g->done[r], hipEventDisableTiming) != hipSuccess) {
-        nbx_group_destroy(g);
+      if (hipSetDevice(g->dev[r]) != hipSuccess || hipEventCreateWithFlags(&g->done[r], hipEventDisableTiming) != hipSuccess)
         return fail(NBX_ERR_DEVICE, "nbx_group_create: hipEventCreate failed");
-      }
       for (int q = 0; q < P; ++q)  // best effort: direct peer access speeds hipMemcpyPeerAsync up
         if (g->dev[q] != g->dev[r]) { (void)hipDeviceEnablePeerAccess(g->dev[q], 0); (void)hipGetLastError(); }
     }
   }
+  owner.g = nullptr;
   *out = g;
   g_err.clear();
   return NBX_OK;
+  });
 }
 
 void nbx_group_destroy(nbx_group* g) {
@@ -934,6 +962,7 @@ int nbx_group_upload(nbx_group* g, const void* px, const void* py, const void* p
 }
 
 int nbx_group_step(nbx_group* g, double dt, int32_t nsteps, double* kenergy_out) {
+  return guarded("nbx_group_step", [&]() -> int {
   if (!g) return fail(NBX_ERR_ARG, "nbx_group_step: group is NULL");
   if (nsteps < 0) return fail(NBX_ERR_ARG, "nbx_group_step: nsteps < 0");
   for (int s = 0; s < nsteps; ++s) {
@@ -965,6 +994,7 @@ int nbx_group_step(nbx_group* g, double dt, int32_t nsteps, double* kenergy_out)
     *kenergy_out = 0.5 * sum;
   }
   return NBX_OK;
+  });
 }
 
 int nbx_group_download(nbx_group* g, void* px, void* py, void* pz, void* vx, void* vy, void* vz) {
