@@ -167,6 +167,7 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   int variant = o.kernel_variant;
   if (variant == NBX_KERNEL_EXACT || variant == NBX_KERNEL_EXACT_FMA) {  // one thread per body, no blocking, no splits, separate integrate kernel
     c->B = 1; c->S = 1; c->jps = c->n_alloc; c->math = MATH_SCALAR; c->variant = variant; c->epi = EPI_SLAB;
+    c->order = NBX_ORDER_REFERENCE;  // one accumulator per body, j ascending: it IS the reference's loop
     c->grid = dim3(ceil_div(c->i_count, kBlock), 1);
     return;
   }
