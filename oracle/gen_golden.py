@@ -37,7 +37,8 @@ CASES = [
 ]
 # BASELINE.json configs[2] / configs[4] size: ~65 s per step here, generated once with
 #   python oracle/gen_golden.py --only f32:262144:7 f64:262144:3
-BIG_CASES = [("f32", 262144, 7), ("f64", 262144, 3)]
+#   python oracle/gen_golden.py --only f32:32768:500     (310 s: the chaotic regime)
+BIG_CASES = [("f32", 262144, 7), ("f64", 262144, 3), ("f32", 32768, 500)]
 
 
 def run_case(prec, n, steps, nsample=8):
