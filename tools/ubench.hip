@@ -12,12 +12,14 @@
 constexpr int ITERS = 2048;
 
 // 16 independent instructions per loop iteration
-template <int OP>
+// HALF: only lanes 0..31 of every wave64 execute the loop (EXEC = low half): does a half-populated wave issue faster?
+template <int OP, bool HALF = false>
 __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, float seed) {
   float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
   float b0 = a0 * 0.5f, b1 = a1 * 0.5f, b2 = a2 * 0.5f, b3 = a3 * 0.5f, b4 = a4 * .5f, b5 = a5 * .5f, b6 = a6 * .5f, b7 = a7 * .5f;
   const float m = 1.0000001f, c = 1e-9f;
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (!HALF || (threadIdx.x & 63) < 32)
   for (int i = 0; i < ITERS; ++i) {
     if constexpr (OP == 0) {  // 16 x v_fma_f32
       asm volatile(
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void k(float* out, unsigned long long* cyc, fl
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-template <int OP>
+template <int OP, bool HALF = false>
 void run(const char* name, int instr_per_iter, int flops_per_iter, int cus) {
   float* out;
   unsigned long long* cyc;
@@ -108,10 +110,10 @@ void run(const char* name, int instr_per_iter, int flops_per_iter, int cus) {
   for (int wps : {1, 2, 4, 8}) {  // waves per SIMD == blocks of 256 per CU
     int blocks = cus * wps;
     CK(hipMalloc(&cyc, sizeof(unsigned long long) * blocks * 4));
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.0f);
+    hipLaunchKernelGGL((k<OP, HALF>), dim3(blocks), dim3(256), 0, 0, out, cyc, 1.0f);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, cyc, 1.0f);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k<OP, HALF>), dim3(blocks), dim3(256), 0, 0, out, cyc, 1.0f);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -142,5 +144,8 @@ int main() {
   run<2>("v_rsq_f32 x16", 16, 16, cus);
   run<3>("14 fma + 2 rsq", 16, 30, cus);
   run<4>("12 pk_fma + 2 rsq", 14, 50, cus);
+  // same streams with only the low 32 lanes active (flops counted for the active half)
+  run<4, true>("12 pk_fma + 2 rsq, EXEC lo32", 14, 25, cus);
+  run<0, true>("v_fma_f32 x16, EXEC lo32", 16, 16, cus);
   return 0;
 }
