@@ -850,6 +850,33 @@ def test_config2_printed_steps_reference_order_vs_reference_arithmetic(nbx):
         assert c.stats()["summation_order"] == nbx.ORDER_REFERENCE
 
 
+_CONFIG2_FIXTURE = os.path.join(ROOT, "tests", "golden", "ver7_f32_n262144_s200.json")
+
+
+@pytest.mark.skipif(not os.path.exists(_CONFIG2_FIXTURE), reason="fixture of the full configs[2] run (hours of the reference's CPU binary) not generated")
+def test_config2_all_200_steps_against_the_real_reference(nbx):
+    """BASELINE.json configs[2] against the reference's OWN binary over the whole run (fixture: `oracle/gen_golden.py --only
+    f32:262144:200`, hours of CPU): the default kernel stays within the 1e-4 gate at every step, the printed rows
+    (s = 50, 100, 150, 200) included, and NBX_KERNEL_EXACT ends on the reference's very bits."""
+    g = load_golden("ver7_f32_n262144_s200.json")
+    ref = np.array(g["kenergy"])
+    with nbx.Context(262144) as c:
+        c.upload(nbx.initial_conditions(262144))
+        e = rel_err(c.step_trace(200), ref)
+        assert c.stats()["summation_order"] == nbx.ORDER_REFERENCE
+    _dump("parity_config2_vs_real_reference.json", {"max": float(e.max()), "printed": {str(s): float(e[s - 1]) for s in (50, 100, 150, 200)},
+                                                    "all_steps": [float(x) for x in e]})
+    assert e.max() < 1e-4, e.max()
+    with nbx.Context(262144, kernel_variant=nbx.KERNEL_EXACT) as c:
+        c.upload(nbx.initial_conditions(262144))
+        ke = c.step_trace(200)
+        d = c.download()
+    for f in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z"):
+        assert _crc(d[f]) == g["final"][f]["crc32"], f
+    assert rel_err(ke, ref).max() < 3e-6
+
+
+
 def test_config3_size_reference_order_vs_reference_arithmetic(nbx):
     """BASELINE.json configs[3]'s n = 1048576 (first 6 steps; the reference would need ~11 min per step)."""
     tr, _ = _side_by_side(nbx, 1048576, 6, chunk=6)
