@@ -109,7 +109,8 @@ def parity_probe(nbx, n, precision):
     """Cheap in-run check against the reference's golden trace when a fixture exists for this n."""
     import numpy as np
     name = {(262144, 32): "ver7_f32_n262144_s7.json", (16384, 32): "ver7_f32_n16384_s500.json",
-            (2000, 32): "ver7_f32_n2000_s500.json"}.get((n, precision))
+            (2000, 32): "ver7_f32_n2000_s500.json", (262144, 64): "ver7_f64_n262144_s3.json",
+            (16384, 64): "ver7_f64_n16384_s60.json"}.get((n, precision))
     if not name:
         return None
     g = json.load(open(os.path.join(ROOT, "tests", "golden", name)))
