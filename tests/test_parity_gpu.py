@@ -873,7 +873,8 @@ def test_config2_all_200_steps_against_the_real_reference(nbx):
         d = c.download()
     for f in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z"):
         assert _crc(d[f]) == g["final"][f]["crc32"], f
-    assert rel_err(ke, ref).max() < 3e-6
+    # same velocities, different sum: the reference reduces m*v^2 in float over its OpenMP threads, here an fp64 tree
+    assert rel_err(ke, ref).max() < 1e-5
 
 
 
