@@ -878,6 +878,35 @@ def test_config2_all_200_steps_against_the_real_reference(nbx):
 
 
 
+_CONFIG3_FIXTURE = os.path.join(ROOT, "tests", "golden", "ver7_f32_n1048576_s3.json")
+
+
+@pytest.mark.skipif(not os.path.exists(_CONFIG3_FIXTURE), reason="fixture of configs[3]'s first steps (40 min of the reference's CPU binary) not generated")
+def test_config3_first_steps_against_the_real_reference(nbx):
+    """BASELINE.json configs[3]'s size (n = 1048576) against the reference's own binary for its first 3 steps (12 min of CPU
+    per step here): one context, 8 logical ranks of 131072 bodies (the 8-GPU partition) and the exact mode."""
+    g = load_golden("ver7_f32_n1048576_s3.json")
+    n, k = g["n"], g["nsteps"]
+    ref = np.array(g["kenergy"])
+    ic = nbx.initial_conditions(n)
+    with nbx.Context(n) as c:
+        c.upload(ic)
+        e1 = rel_err(c.step_trace(k), ref)
+        assert c.stats()["summation_order"] == nbx.ORDER_REFERENCE
+    with nbx.Group(n, 32, n_ranks=8) as grp:
+        grp.upload(ic)
+        e8 = abs(grp.step(k) - ref[-1]) / ref[-1]
+    with nbx.Context(n, kernel_variant=nbx.KERNEL_EXACT) as c:
+        c.upload(ic)
+        ke = c.step_trace(k)
+        d = c.download()
+    _dump("parity_config3_vs_real_reference.json", {"one_context": [float(x) for x in e1], "eight_logical_ranks_last_step": float(e8),
+                                                    "exact_mode_kenergy": [float(x) for x in rel_err(ke, ref)]})
+    assert e1.max() < 1e-5 and e8 < 1e-5, (e1, e8)
+    for f in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z"):
+        assert _crc(d[f]) == g["final"][f]["crc32"], f
+
+
 def test_config3_size_reference_order_vs_reference_arithmetic(nbx):
     """BASELINE.json configs[3]'s n = 1048576 (first 6 steps; the reference would need ~11 min per step)."""
     tr, _ = _side_by_side(nbx, 1048576, 6, chunk=6)
