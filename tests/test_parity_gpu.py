@@ -907,6 +907,29 @@ def test_config3_first_steps_against_the_real_reference(nbx):
         assert _crc(d[f]) == g["final"][f]["crc32"], f
 
 
+_CONFIG4_FIXTURE = os.path.join(ROOT, "tests", "golden", "ver7_f64_n262144_s50.json")
+
+
+@pytest.mark.skipif(not os.path.exists(_CONFIG4_FIXTURE), reason="fixture of 50 fp64 steps at n = 262144 (over an hour of the reference's CPU binary) not generated")
+def test_config4_fp64_first_printed_row_against_the_real_reference(nbx):
+    """BASELINE.json configs[4] (n = 262144, fp64 variant, tolerance 1e-10) up to the first printed row (s = 50) against the
+    reference's own source built as the fp64 variant; exact mode CRC-identical after the 50 steps."""
+    g = load_golden("ver7_f64_n262144_s50.json")
+    ref = np.array(g["kenergy"])
+    with nbx.Context(262144, 64) as c:
+        c.upload(nbx.initial_conditions(262144, 64))
+        e = rel_err(c.step_trace(50), ref)
+    _dump("parity_config4_vs_real_reference.json", {"max": float(e.max()), "step50": float(e[49]), "all_steps": [float(x) for x in e]})
+    assert e.max() < 1e-10, e.max()
+    with nbx.Context(262144, 64, kernel_variant=nbx.KERNEL_EXACT) as c:
+        c.upload(nbx.initial_conditions(262144, 64))
+        ke = c.step_trace(50)
+        d = c.download()
+    for f in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z"):
+        assert _crc(d[f]) == g["final"][f]["crc32"], f
+    assert rel_err(ke, ref).max() < 1e-13
+
+
 def test_config3_size_reference_order_vs_reference_arithmetic(nbx):
     """BASELINE.json configs[3]'s n = 1048576 (first 6 steps; the reference would need ~11 min per step)."""
     tr, _ = _side_by_side(nbx, 1048576, 6, chunk=6)
