@@ -128,6 +128,8 @@ class ShardedSimulation:
         self.engine = factory(self.n, precision, self.i_begin, self.i_count, self.n_alloc, **opts)
         self.steps_done = 0
         self.bytes_gathered = 0
+        self._staged = False      # out-of-place fallback of the all-gather (see _all_gather_in_place)
+        self._stage_buf = None
 
     def upload(self, state):
         self.engine.upload(state)
@@ -142,8 +144,20 @@ class ShardedSimulation:
             host = torch.empty(full.numel(), dtype=full.dtype)
             self.dist.all_gather_into_tensor(host, own.cpu())
             full.copy_(host)
-        else:
-            self.dist.all_gather_into_tensor(full, own)
+        elif not self._staged:
+            try:
+                self.dist.all_gather_into_tensor(full, own)
+            except (RuntimeError, ValueError) as e:
+                # an argument-level refusal of the aliasing output (never seen; the 1-rank RCCL rehearsal accepts it):
+                # keep the run alive with an out-of-place gather + one device copy, and say so once
+                import sys
+                print("sharded: in-place all-gather refused (%s); staging through a second buffer" % e, file=sys.stderr)
+                self._staged = True
+        if self._staged and not (full.is_cuda and self.dist.get_backend() != "nccl"):
+            if self._stage_buf is None:
+                self._stage_buf = torch.empty_like(full)
+            self.dist.all_gather_into_tensor(self._stage_buf, own.clone())
+            full.copy_(self._stage_buf)
         self.bytes_gathered += nb * (self.world - 1)
 
     def step(self, nsteps=1, dt=None):

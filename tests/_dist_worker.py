@@ -78,6 +78,8 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     sim = sharded.ShardedSimulation(n, 32, dist=dist, engine_factory=OracleEngine)
+    if os.environ.get("NBX_TEST_STAGED_GATHER"):  # the out-of-place fallback of the all-gather
+        sim._staged = True
     ic = O.init_state(n)
     sim.upload({f: getattr(ic, f) for f in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass")})
     ke = []

@@ -39,11 +39,13 @@ def test_block_partition_properties():
         sharded.block_partition(10, 2, 2)
 
 
-@pytest.mark.parametrize("n,world", [(1000, 2), (1500, 3)])
-def test_gloo_ranks_reproduce_single_process_trace(oracle, tmp_path, n, world):
+@pytest.mark.parametrize("n,world,staged", [(1000, 2, False), (1500, 3, False), (1000, 2, True)])
+def test_gloo_ranks_reproduce_single_process_trace(oracle, tmp_path, n, world, staged):
     steps = 15
     out = str(tmp_path / "res")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="2")
+    if staged:  # sharded.py's out-of-place fallback (second buffer + copy) must give the same positions
+        env["NBX_TEST_STAGED_GATHER"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
            os.path.join(ROOT, "tests", "_dist_worker.py"), str(n), str(steps), out]
