@@ -192,7 +192,7 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
     if (B != 1 && B != 2 && B != 4 && B != 8) B = 0;
     if (B > maxBr) B = maxBr;
     // measured (profiles/r01_reference_order_shapes.txt): the chains are the owned bodies, so few bodies want few per lane
-    if (B == 0) B = c->i_count >= 393216 ? 4 : (c->i_count >= 98304 ? 2 : 1);
+    if (B == 0) B = c->i_count >= 262144 ? 4 : (c->i_count >= 98304 ? 2 : 1);
     c->B = B; c->S = 1; c->jps = c->n_alloc; c->variant = variant;
     c->math = (c->precision == 32 && B >= 2) ? MATH_PACKED : MATH_SCALAR;
     c->epi = o.fused_epilogue == 2 ? EPI_SLAB : EPI_ROW;
