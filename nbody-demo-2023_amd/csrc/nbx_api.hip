@@ -155,6 +155,26 @@ ForceLauncher<T> pick_force(const nbx_ctx* c, int epi) {
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
 int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
+// Bodies per lane of the reference-order kernel (one chain per owned body, S = 1).  Its run time is quantised: the
+// ceil(own / (256 B)) workgroups are spread over the CUs, and a launch takes as long as the fullest CU, which holds
+// r = ceil(workgroups / CUs) of them.  Measured on MI355X at n = 1048576 (profiles/r01_reference_order_thresholds.txt), ms for
+// r = 1, 2, 3, ...: B = 1: 30.9, 48.5, 70.5, 91, 111.5 (plain VALU ops);  B = 2: 38.0, 65.5, 96.5;  B = 4: 66, 123 --
+// linear in r after the first workgroup.  Pick the B with the smallest estimate; ties go to the larger B (fewer
+// workgroups stream the j records).  Only the ratios matter, so the table serves every n.
+int reference_order_bodies_per_lane(int own, int cus, int max_b) {
+  static const struct { int b; double first, next; } kCost[] = {{1, 30.9, 20.0}, {2, 38.0, 28.5}, {4, 66.0, 57.0}};
+  int best = 1;
+  double best_t = 0.0;
+  for (const auto& k : kCost) {
+    if (k.b > max_b) continue;
+    const int wgs = ceil_div(own, kBlock * k.b);
+    const int r = std::max(1, ceil_div(wgs, std::max(1, cus)));
+    const double t = k.first + k.next * (r - 1);
+    if (best_t == 0.0 || t <= best_t * 1.01) { best = k.b; best_t = std::min(t, best_t == 0.0 ? t : best_t); }
+  }
+  return best;
+}
+
 // Launch shape.  Measured with tools/kbench on MI355X (profiles/r01_kbench_*): the force kernel is
 // VALU-issue bound and wants all 8 wave slots of every SIMD filled, i.e. >= 8192 workgroups of 256
 // threads (32 per CU).  Fastest shape from n = 2k to 1M: j records in SGPRs, the four waves of a
@@ -191,8 +211,7 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
     const int maxBr = c->precision == 32 ? 8 : 4;
     if (B != 1 && B != 2 && B != 4 && B != 8) B = 0;
     if (B > maxBr) B = maxBr;
-    // measured (profiles/r01_reference_order_shapes.txt): the chains are the owned bodies, so few bodies want few per lane
-    if (B == 0) B = c->i_count >= 262144 ? 4 : (c->i_count >= 98304 ? 2 : 1);
+    if (B == 0) B = reference_order_bodies_per_lane(c->i_count, cus, maxBr);
     c->B = B; c->S = 1; c->jps = c->n_alloc; c->variant = variant;
     c->math = (c->precision == 32 && B >= 2) ? MATH_PACKED : MATH_SCALAR;
     c->epi = o.fused_epilogue == 2 ? EPI_SLAB : EPI_ROW;
