@@ -38,6 +38,7 @@ enum {
 };
 
 enum { NBX_ORDER_AUTO = 0, NBX_ORDER_REFERENCE = 1, NBX_ORDER_TREE = 2 };
+enum { NBX_LOOP_AUTO = 0, NBX_LOOP_CXX = 1, NBX_LOOP_ASM = 2 };
 
 /* kernel_variant values */
 enum {
@@ -91,7 +92,11 @@ typedef struct nbx_opts {
                                   sum, whatever slice of the bodies this context owns), TREE up to there (the two agree
                                   with the reference within the 1e-4 gate: 2e-5 over 500 steps at n = 131072) and for fp64
                                   (its summation noise is ~1e-13, far inside the 1e-10 gate either way) */
-  int32_t reserved[3];
+  int32_t inner_loop;      /* scheduling of the SGPR kernel's j loop: 0 = NBX_LOOP_AUTO (the hand-scheduled gfx950 loop wherever
+                              an instance exists: packed fp32, kernel_variant SGPR, 2 or 4 bodies per lane), 1 = NBX_LOOP_CXX
+                              (always the compiler-scheduled C++ loop), 2 = NBX_LOOP_ASM (fail if no instance fits the shape).
+                              Both loops perform the same operations in the same order: results are bit-identical */
+  int32_t reserved[2];
 } nbx_opts;
 
 typedef struct nbx_stats_t {
@@ -108,7 +113,7 @@ typedef struct nbx_stats_t {
   char    device_name[64];
   int64_t graph_replays;       /* hipGraph launches issued by nbx_step (each covers up to 20 steps) */
   int32_t use_graph;           /* 1 if nbx_step replays windows from a hipGraph */
-  int32_t reserved;
+  int32_t inner_loop;          /* NBX_LOOP_CXX or NBX_LOOP_ASM actually in use by the step kernel */
 } nbx_stats_t;
 
 /* Text of the last error on the calling thread ("" if none). Never NULL. */

@@ -62,6 +62,7 @@ constexpr int kTreeOrderMaxN = 131072;
 struct nbx_ctx {
   int n = 0, n_alloc = 0, i_begin = 0, i_count = 0, own_pad = 0, precision = 32;
   int B = 1, S = 1, jps = 0, variant = NBX_KERNEL_LDS, epi = EPI_SLAB, math = MATH_SCALAR, order = NBX_ORDER_TREE;
+  int loop = LOOP_CXX;  // LOOP_ASM where the hand-scheduled j loop is in use
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -99,16 +100,29 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // kernel dispatch
 // ------------------------------------------------------------------------------------------
-template <typename T, int B, int JSRC, int EPI, int MATH, bool WS>
+template <typename T, int B, int JSRC, int EPI, int MATH, bool WS, int LOOP = LOOP_CXX>
 void launch_force_t(const ForceArgs<T>& a, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((force_kernel<T, B, JSRC, EPI, 1, MATH, WS>), grid, dim3(kBlock), 0, st, a);
+  hipLaunchKernelGGL((force_kernel<T, B, JSRC, EPI, 1, MATH, WS, LOOP>), grid, dim3(kBlock), 0, st, a);
 }
+
+// does a hand-scheduled (LOOP_ASM) instance exist for this combination?
+template <typename T, int JSRC, int EPI, int MATH, bool WS>
+constexpr bool kHasAsmLoop = sizeof(T) == 4 && JSRC == JSRC_SGPR && MATH == MATH_PACKED && !WS && EPI != EPI_LAST;
 
 template <typename T>
 using ForceLauncher = void (*)(const ForceArgs<T>&, dim3, hipStream_t);
 
 template <typename T, int JSRC, int EPI, int MATH, bool WS>
-ForceLauncher<T> pick_b(int B) {
+ForceLauncher<T> pick_b(int B, int loop) {
+  if constexpr (kHasAsmLoop<T, JSRC, EPI, MATH, WS>) {
+    if (loop == LOOP_ASM) {
+      if (B == 2) return launch_force_t<T, 2, JSRC, EPI, MATH, WS, LOOP_ASM>;
+      if (B == 4) return launch_force_t<T, 4, JSRC, EPI, MATH, WS, LOOP_ASM>;
+      return nullptr;
+    }
+  } else if (loop == LOOP_ASM) {
+    return nullptr;
+  }
   switch (B) {
     case 1:
       if constexpr (MATH == MATH_SCALAR) return launch_force_t<T, 1, JSRC, EPI, MATH, WS>;
@@ -128,28 +142,35 @@ ForceLauncher<T> pick_b(int B) {
 }
 
 template <typename T, int JSRC, int MATH, bool WS>
-ForceLauncher<T> pick_epi(int B, int epi) {
-  if (epi == EPI_LAST) return pick_b<T, JSRC, EPI_LAST, MATH, WS>(B);
+ForceLauncher<T> pick_epi(int B, int epi, int loop) {
+  if (epi == EPI_LAST) return pick_b<T, JSRC, EPI_LAST, MATH, WS>(B, loop);
   if (epi == EPI_ROW) {
-    if constexpr (!WS) return pick_b<T, JSRC, EPI_ROW, MATH, WS>(B);
+    if constexpr (!WS) return pick_b<T, JSRC, EPI_ROW, MATH, WS>(B, loop);
     return nullptr;
   }
-  return pick_b<T, JSRC, EPI_SLAB, MATH, WS>(B);
+  return pick_b<T, JSRC, EPI_SLAB, MATH, WS>(B, loop);
 }
 
 template <typename T, int MATH>
-ForceLauncher<T> pick(int B, int variant, int epi) {
-  if (variant == NBX_KERNEL_SGPRW) return pick_epi<T, JSRC_SGPR, MATH, true>(B, epi);
-  if (variant == NBX_KERNEL_SGPR) return pick_epi<T, JSRC_SGPR, MATH, false>(B, epi);
-  return pick_epi<T, JSRC_LDS, MATH, false>(B, epi);
+ForceLauncher<T> pick(int B, int variant, int epi, int loop) {
+  if (variant == NBX_KERNEL_SGPRW) return pick_epi<T, JSRC_SGPR, MATH, true>(B, epi, loop);
+  if (variant == NBX_KERNEL_SGPR) return pick_epi<T, JSRC_SGPR, MATH, false>(B, epi, loop);
+  return pick_epi<T, JSRC_LDS, MATH, false>(B, epi, loop);
+}
+
+// Does the hand-scheduled loop exist for this shape?  (mirror of kHasAsmLoop for run-time shape decisions)
+bool asm_loop_available(const nbx_ctx* c, int epi) {
+  return c->precision == 32 && c->variant == NBX_KERNEL_SGPR && c->math == MATH_PACKED && (c->B == 2 || c->B == 4) && epi != EPI_LAST;
 }
 
 template <typename T>
 ForceLauncher<T> pick_force(const nbx_ctx* c, int epi) {
+  // nbx_accel runs the EPI_SLAB form of a context whose step kernel may be another epilogue: decide per call
+  const int loop = (c->loop == LOOP_ASM && asm_loop_available(c, epi)) ? LOOP_ASM : LOOP_CXX;
   if constexpr (sizeof(T) == 4) {
-    if (c->math == MATH_PACKED) return pick<float, MATH_PACKED>(c->B, c->variant, epi);
+    if (c->math == MATH_PACKED) return pick<float, MATH_PACKED>(c->B, c->variant, epi, loop);
   }
-  return pick<T, MATH_SCALAR>(c->B, c->variant, epi);
+  return pick<T, MATH_SCALAR>(c->B, c->variant, epi, loop);
 }
 
 int ceil_div(int a, int b) { return (a + b - 1) / b; }
@@ -514,6 +535,11 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
     c->own_stream = true;
   }
   auto_shape(c, o);
+  if (o.inner_loop != NBX_LOOP_AUTO && o.inner_loop != NBX_LOOP_CXX && o.inner_loop != NBX_LOOP_ASM)
+    return fail(NBX_ERR_ARG, "nbx_create: inner_loop must be NBX_LOOP_AUTO, NBX_LOOP_CXX or NBX_LOOP_ASM");
+  c->loop = (o.inner_loop != NBX_LOOP_CXX && asm_loop_available(c, c->epi)) ? LOOP_ASM : LOOP_CXX;
+  if (o.inner_loop == NBX_LOOP_ASM && c->loop != LOOP_ASM)
+    return fail(NBX_ERR_ARG, "nbx_create: no hand-scheduled loop for this shape (needs fp32, kernel_variant SGPR, 2 or 4 bodies per lane)");
   // use_graph: 0 auto (launch-bound sizes only: < ~0.3 ms of pair work per step), 1 on, 2 off;
   // capture needs a stream of our own
   {
@@ -789,6 +815,7 @@ int nbx_stats(nbx_ctx* c, nbx_stats_t* s) {
   s->pairs_per_launch = (double)c->i_count * (double)c->n;
   s->graph_replays = c->graph_replays;
   s->use_graph = c->use_graph ? 1 : 0;
+  s->inner_loop = c->loop == LOOP_ASM ? NBX_LOOP_ASM : NBX_LOOP_CXX;
   // some boxes report an empty marketing name; fall back to / append the ISA name
   std::snprintf(s->device_name, sizeof(s->device_name), "%s%s%s", c->prop.name, c->prop.name[0] ? " " : "",
                 c->prop.gcnArchName);

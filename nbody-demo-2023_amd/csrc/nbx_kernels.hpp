@@ -199,6 +199,12 @@ __device__ __forceinline__ void sgpr_wait(SgprBatch<T> (&b)[G]) {
 }
 
 enum : int { MATH_SCALAR = 0, MATH_PACKED = 1 };
+// How the SGPR kernel's j loop is scheduled: LOOP_CXX = hipcc schedules the C++ loop below; LOOP_ASM = the hand-scheduled
+// gfx950 loop of nbx_sgpr_loop.inc (packed fp32, B = 2 or 4, no wave split): same operations in the same order, hence
+// the same bits (tests compare the two), but no s_mov splats, one pointer update per trip and 8-byte aligned VOP3P code:
+// worth 13 % when a SIMD holds a single wave, where every scalar instruction costs a full 4-cycle issue slot.
+enum : int { LOOP_CXX = 0, LOOP_ASM = 1 };
+#include "nbx_sgpr_loop.inc"
 // What a workgroup does with its accelerations:
 //   EPI_SLAB  write them to its split's slab (the separate integrate_kernel, or nbx_accel, consumes the slabs)
 //   EPI_ROW   single split (gridDim.y == 1): integrate its bodies directly, no slab
@@ -237,6 +243,12 @@ struct IBodies<float, B, MATH_PACKED> {
   __device__ __forceinline__ void get(int b, float& x, float& y, float& z) const {
     x = ax[b / 2][b & 1]; y = ay[b / 2][b & 1]; z = az[b / 2][b & 1];
   }
+  // all records of [first, last) in ascending order through the hand-scheduled loop (LOOP_ASM)
+  __device__ __forceinline__ void apply_range_asm(const float4* first, const float4* last) {
+    static_assert(B == 2 || B == 4, "the asm loop exists for 2 and 4 bodies per lane");
+    if constexpr (B == 2) sgpr_loop_asm_b2(first, last, xi[0], yi[0], zi[0], ax[0], ay[0], az[0]);
+    else sgpr_loop_asm_b4(first, last, xi[0], yi[0], zi[0], xi[1], yi[1], zi[1], ax[0], ay[0], az[0], ax[1], ay[1], az[1]);
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -248,10 +260,12 @@ struct IBodies<float, B, MATH_PACKED> {
 //     j range; the four partial sums are added in wave order through LDS.  Four times the workgroups
 //     for the same number of partial-acceleration slabs.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int B, int JSRC, int EPI, int MINW, int MATH = MATH_SCALAR, bool WSPLIT = false>
+template <typename T, int B, int JSRC, int EPI, int MINW, int MATH = MATH_SCALAR, bool WSPLIT = false, int LOOP = LOOP_CXX>
 __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> a) {
   using T4 = typename V4<T>::type;
   static_assert(!WSPLIT || (JSRC == JSRC_SGPR && EPI != EPI_ROW), "wave split exists for the SGPR kernel with slabs only");
+  static_assert(LOOP == LOOP_CXX || (JSRC == JSRC_SGPR && MATH == MATH_PACKED && !WSPLIT && sizeof(T) == 4 && (B == 2 || B == 4)),
+                "the hand-scheduled loop exists for the packed fp32 SGPR kernel with 2 or 4 bodies per lane");
   const int t = threadIdx.x;
   constexpr int kStride = WSPLIT ? 64 : kBlock;  // distance between a lane's consecutive bodies
   const int base = blockIdx.x * (kStride * B) + (WSPLIT ? (t & 63) : t);
@@ -296,6 +310,9 @@ __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> 
       __syncthreads();  // one barrier per tile: readers of `cur` done, writers of `cur^1` done
       cur ^= 1;
     }
+  } else if constexpr (LOOP == LOOP_ASM) {
+    // j range = a positive multiple of kSgprAsmTrip<B> records (the host rounds j_per_split to 32; n_alloc is a multiple of 256)
+    if (j0 < j1) ib.apply_range_asm(a.posm + j0, a.posm + j1);
   } else {
     // Wave-uniform j index => the records travel by s_load_dwordx16 (64 B = kSgprBatch records) into
     // SGPRs and feed the VALU as scalar operands: no LDS bandwidth, no VGPRs, no barrier.  Two

@@ -8,9 +8,15 @@
 #ifndef NBX_HOST_GSIMULATION_HPP
 #define NBX_HOST_GSIMULATION_HPP
 
+// the standard headers the reference's GSimulation.hpp provides to its includers (ver5_all/GSimulation.hpp:25-30;
+// ver5_all/main.cpp uses std::cout and std::string without including anything else)
+#include <iomanip>
+#include <iostream>
+#include <random>
 #include <string>
 
 #include "Particle.hpp"
+#include "cpu_time.hpp"
 
 struct nbx_ctx;
 
@@ -32,8 +38,17 @@ class GSimulation {
   int get_thread_dim0() { return _thread_dim0; }
   int get_thread_dim1() { return _thread_dim1; }
   int get_cpu_ratio() const { return (int)_cpu_ratio; }
-  void set_devices(int N) { _devices = N; }
+  void set_devices(int N) { _devices = N; }  // 1 = "cpu" (refused by start(): no CPU engine), 2 = "gpu", 3 = "cpu+gpu"
   int get_devices() { return _devices; }
+
+  // ver5_all/GSimulation.hpp:60-65 -- the MPI surface.  One process: rank 0 of 1 owning all bodies.  Several
+  // processes (one per GPU, NBODY_WORLD / NBODY_RANK or torchrun's WORLD_SIZE / RANK in the environment): the
+  // i-block partition of include/nbx.h, see init_mpi() in GSimulation.cpp.
+  int world_rank;
+  int world_size;
+  int npp;          // bodies this process owns
+  int* npp_global;  // [world_size] bodies per rank
+  void init_mpi();
 
   // read-only views for embedding code and tests (the reference keeps these private)
   const ParticleSoA* particle_store() const { return particles; }

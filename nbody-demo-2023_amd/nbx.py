@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("NBX_LIB") or os.path.join(_HERE, "libnbx.so")
 
 NBX_OK, NBX_ERR_ARG, NBX_ERR_DEVICE, NBX_ERR_STATE, NBX_ERR_ALLOC = 0, -1, -2, -3, -4
 ORDER_AUTO, ORDER_REFERENCE, ORDER_TREE = 0, 1, 2
+LOOP_AUTO, LOOP_CXX, LOOP_ASM = 0, 1, 2
 KERNEL_AUTO, KERNEL_LDS, KERNEL_SGPR, KERNEL_SGPRW, KERNEL_EXACT, KERNEL_EXACT_FMA = 0, 1, 2, 3, 4, 5
 
 # every symbol include/nbx.h declares (tests check the library exports each of them)
@@ -39,7 +40,7 @@ class Opts(ctypes.Structure):
         ("i_begin", ctypes.c_int32), ("i_count", ctypes.c_int32), ("n_alloc", ctypes.c_int32),
         ("bodies_per_lane", ctypes.c_int32), ("j_split", ctypes.c_int32), ("kernel_variant", ctypes.c_int32),
         ("fused_epilogue", ctypes.c_int32), ("use_graph", ctypes.c_int32), ("external_stream", ctypes.c_int32),
-        ("summation_order", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3),
+        ("summation_order", ctypes.c_int32), ("inner_loop", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2),
     ]
 
 
@@ -52,7 +53,7 @@ class Stats(ctypes.Structure):
         ("cu_count", ctypes.c_int32), ("clock_mhz", ctypes.c_int32), ("steps_done", ctypes.c_int64),
         ("force_launches_timed", ctypes.c_int64), ("force_ms_total", ctypes.c_double),
         ("pairs_per_launch", ctypes.c_double), ("device_name", ctypes.c_char * 64),
-        ("graph_replays", ctypes.c_int64), ("use_graph", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("graph_replays", ctypes.c_int64), ("use_graph", ctypes.c_int32), ("inner_loop", ctypes.c_int32),
     ]
 
     def asdict(self):

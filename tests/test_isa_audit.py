@@ -17,10 +17,19 @@ from conftest import ROOT
 SRC = os.path.join(ROOT, "nbody-demo-2023_amd", "csrc", "nbx_api.hip")
 
 
+def _shipped_hipflags():
+    """The flags libnbx.so is built with (top-level Makefile, HIPFLAGS): the audited ISA must be the executed ISA."""
+    mk = open(os.path.join(ROOT, "Makefile")).read()
+    arch = re.search(r"^ARCH\s*\?=\s*(\S+)", mk, re.M).group(1)
+    flags = re.search(r"^HIPFLAGS\s*=\s*(.+)$", mk, re.M).group(1).replace("$(ARCH)", arch).split()
+    assert "--offload-arch=gfx950" in flags and "-O3" in flags, flags
+    return flags
+
+
 @pytest.fixture(scope="module")
 def kernels(tmp_path_factory):
     out = tmp_path_factory.mktemp("isa") / "nbx_api.s"
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", SRC, "-o", str(out)])
+    subprocess.check_call(["hipcc"] + _shipped_hipflags() + ["-S", "--cuda-device-only", SRC, "-o", str(out)])
     txt = open(out).read()
     ks = {}
     for m in re.finditer(r"\n(_ZN3nbx\w+):(.*?)\n\s+s_endpgm.*?\.amdhsa_kernel \1(.*?)\.end_amdhsa_kernel", txt, re.S):
@@ -130,3 +139,25 @@ def test_euler_update_is_not_fma_contracted(kernels):
         seen += 1
         assert not re.search(r"\bv_(pk_)?fma(c|ak|mk)?_f(32|64)\b", body), name
     assert seen == 2
+
+
+def test_generated_asm_loop_is_in_sync_with_its_generator(tmp_path):
+    """csrc/nbx_sgpr_loop.inc is committed (the build needs no python); it must be what tools/gen_sgpr_loop.py writes.
+    The generator itself asserts the two structural rules of the stream: 8-byte instructions on 8-byte offsets, and no
+    VALU instruction reading a register written by the instruction just before it."""
+    out = tmp_path / "loop.inc"
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_sgpr_loop.py"), str(out)])
+    assert open(out).read() == open(os.path.join(ROOT, "nbody-demo-2023_amd", "csrc", "nbx_sgpr_loop.inc")).read()
+
+
+def test_hand_scheduled_instances_have_no_scalar_moves_in_the_loop(kernels):
+    seen = 0
+    for name, (body, _) in kernels.items():
+        if not re.search(r"force_kernelIfLi[24]ELi2ELi[01]ELi1ELi1ELb0ELi1E", name):
+            continue
+        seen += 1
+        asm = body[body.index("#ASMSTART"):body.index("#ASMEND")]
+        loop = asm[asm.index("1:"):]
+        assert "s_mov_b32" not in loop and "s_mov_b64" not in loop, name
+        assert loop.count("s_load_dwordx16") in (4, 8) and loop.count("v_rsq_f32") == 64, name
+    assert seen == 4, seen

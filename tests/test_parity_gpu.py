@@ -1034,3 +1034,43 @@ def test_randomized_shapes_orders_and_sizes_against_exact_mode(nbx):
                 assert abs(p1 - p2) <= 2e-5 * abs(p2) + 1e-300, (n, prec, opts, sl)
         tried += 1
     assert tried >= 60
+
+
+# ---- the hand-scheduled j loop (nbx_sgpr_loop.inc) against the compiler-scheduled one ------------------------------
+@pytest.mark.parametrize("n,own,steps", [(2000, 2000, 40), (4099, 4099, 25), (16384, 16384, 12), (65536, 65536, 4), (300, 300, 30),
+                                          (262144, 32768, 2)])
+@pytest.mark.parametrize("B", [2, 4])
+def test_hand_scheduled_loop_is_bit_equal_to_the_compiled_loop(nbx, n, own, steps, B):
+    """inner_loop = NBX_LOOP_ASM runs the same operations in the same order as the C++ loop: accelerations, trajectories
+    and energies must agree bit for bit, for the row epilogue (reference order), for slabs (j-splits) and on a slice.
+    This is also the hazard check of the asm stream: a consumer issued too close to its producer would change bits."""
+    ic = nbx.initial_conditions(n)
+    for shape in (dict(j_split=1), dict(j_split=1, fused_epilogue=2), dict(j_split=3), dict(j_split=16)):
+        res = []
+        for loop in (nbx.LOOP_ASM, nbx.LOOP_CXX):
+            with nbx.Context(n, 32, kernel_variant=nbx.KERNEL_SGPR, bodies_per_lane=B, inner_loop=loop, use_graph=2,
+                             i_begin=0, i_count=own, n_alloc=n, **shape) as c:
+                c.upload(ic)
+                acc = c.accel()
+                for _ in range(steps):
+                    c.step_local()
+                    c.commit()
+                part = c.kenergy_partial()
+                st = c.stats()
+                assert st["inner_loop"] == loop and st["bodies_per_lane"] == B and st["kernel_variant"] == nbx.KERNEL_SGPR
+                res.append((acc, c.download(), part))
+        for k in range(3):
+            assert np.array_equal(res[0][0][k], res[1][0][k]), (shape, "acc", k)
+        for f in res[0][1]:
+            assert np.array_equal(res[0][1][f], res[1][1][f]), (shape, f)
+        assert res[0][2] == res[1][2], shape
+
+
+def test_hand_scheduled_loop_is_the_default_where_it_exists(nbx):
+    with nbx.Context(262144, 32) as c:  # configs[2]: reference order, SGPR kernel, packed math
+        st = c.stats()
+        assert st["summation_order"] == nbx.ORDER_REFERENCE and st["inner_loop"] == nbx.LOOP_ASM
+    with nbx.Context(4099, 32, kernel_variant=nbx.KERNEL_LDS) as c:
+        assert c.stats()["inner_loop"] == nbx.LOOP_CXX
+    with pytest.raises(nbx.NbxError):
+        nbx.Context(4099, 64, inner_loop=nbx.LOOP_ASM)  # no fp64 instance

@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""gen_sgpr_loop.py -- writes nbody-demo-2023_amd/csrc/nbx_sgpr_loop.inc: the hand-scheduled gfx950 inner loop of
+the packed-fp32 SGPR force kernel (nbx_kernels.hpp, JSRC_SGPR + MATH_PACKED, B = 2 or 4 bodies per lane).
+
+Why asm (measured with tools/ubench2.x on MI355X, profiles/r02_ubench2_*.txt):
+  * ONE wave per SIMD is what the reference summation order leaves a rank that owns 131072 of 1M bodies.  A lone
+    wave issues one instruction per 4 cycles whatever it is: v_pk_*_f32 4, v_rsq_f32 8, and every SALU instruction
+    (s_mov, s_add, s_waitcnt, ...) a full 4-cycle slot too; dependent VALU instructions do not stall.
+  * hipcc's loop spends ~1.7 s_mov per j record on odd-element splats plus 9 address instructions per 16 records:
+    1192 cycles per 16 records against 1024 of VALU work.
+  * An 8-byte VOP3P instruction at an address = 4 mod 8 costs ~0.6 cycle extra on average (70 per 112): 4-byte
+    instructions must come in pairs.
+The loop below keeps the arithmetic of pair2() bit for bit (same operations, same order of summation), reads the odd
+record elements through op_sel (no s_mov), addresses the scalar loads with immediate offsets from one pointer that
+advances once per trip, pairs every 4-byte instruction with another one, and keeps every producer at least two
+instructions away from its consumer (gfx940-family VALU hazards need one wait state after a transcendental or packed
+result; nothing is inserted inside an asm statement, so the order below IS the guarantee).
+
+Register plan (explicit, all clobbered):  temporaries v[T:T+23] = two slots x {dx dy dz r2 q s};  j ring
+s[36:67] (group A: 8 records) and s[68:99] (group B);  s[30:31] = pointer (biased by -TRIP bytes so every immediate
+offset is positive), s[28:29] = end value of that pointer, s[34] = softening.
+"""
+import os
+import sys
+
+TBASE = 40            # first temporary VGPR (even)
+RING_A, RING_B = 36, 68
+SP, SE, SEPS = 30, 28, 34
+NEG = "neg_lo:[0,1] neg_hi:[0,1]"
+
+
+def tmp(slot, k):
+    b = TBASE + 12 * slot + 2 * k
+    return "v[%d:%d]" % (b, b + 1), "v%d" % b, "v%d" % (b + 1)
+
+
+def record_ops(slot, rbase, xi, yi, zi, ax, ay, az):
+    """The 14 instructions of pair2() for one packed pair of i-bodies and the record in s[rbase:rbase+3]."""
+    xy, zw = "s[%d:%d]" % (rbase, rbase + 1), "s[%d:%d]" % (rbase + 2, rbase + 3)
+    (dx, _, _), (dy, _, _), (dz, _, _), (r2, r2l, r2h), (q, _, _), (s, _, _) = (tmp(slot, k) for k in range(6))
+    head = [
+        "v_pk_add_f32 %s, %s, %s op_sel_hi:[0,1] %s" % (dx, xy, xi, NEG),
+        "v_pk_add_f32 %s, %s, %s op_sel:[1,0] op_sel_hi:[1,1] %s" % (dy, xy, yi, NEG),
+        "v_pk_add_f32 %s, %s, %s op_sel_hi:[0,1] %s" % (dz, zw, zi, NEG),
+        "v_pk_fma_f32 %s, %s, %s, s[%d:%d] op_sel_hi:[1,1,0]" % (r2, dz, dz, SEPS, SEPS + 1),
+        "v_pk_fma_f32 %s, %s, %s, %s" % (r2, dy, dy, r2),
+        "v_pk_fma_f32 %s, %s, %s, %s" % (r2, dx, dx, r2),
+        "v_rsq_f32_e32 %s, %s" % (r2l, r2l),
+        "v_rsq_f32_e32 %s, %s" % (r2h, r2h),
+        "v_pk_mul_f32 %s, %s, %s" % (q, r2, r2),
+        "v_pk_mul_f32 %s, %s, %s op_sel:[1,0] op_sel_hi:[1,1]" % (s, zw, r2),
+        "v_pk_mul_f32 %s, %s, %s" % (s, s, q),
+    ]
+    tail = [
+        "v_pk_fma_f32 %s, %s, %s, %s" % (ax, dx, s, ax),
+        "v_pk_fma_f32 %s, %s, %s, %s" % (ay, dy, s, ay),
+        "v_pk_fma_f32 %s, %s, %s, %s" % (az, dz, s, az),
+    ]
+    return head, tail
+
+
+def zip2(a, b):
+    out = []
+    for x, y in zip(a, b):
+        out += [x, y]
+    return out
+
+
+def group_ops(B, ring):
+    """VALU instructions that apply the 8 records of one ring group, in ascending record order per accumulator."""
+    out = []
+    if B == 2:
+        I = ("%3", "%4", "%5", "%0", "%1", "%2")
+        for u in range(0, 8, 2):  # two records in flight; the accumulator updates of record u precede those of u+1
+            ha, ta = record_ops(0, ring + 4 * u, *I)
+            hb, tb = record_ops(1, ring + 4 * (u + 1), *I)
+            out += zip2(ha, hb) + ta + tb
+    else:
+        I0 = ("%6", "%7", "%8", "%0", "%1", "%2")
+        I1 = ("%9", "%10", "%11", "%3", "%4", "%5")
+        for u in range(8):        # one record, the two packed pairs in flight
+            ha, ta = record_ops(0, ring + 4 * u, *I0)
+            hb, tb = record_ops(1, ring + 4 * u, *I1)
+            out += zip2(ha, hb) + zip2(ta, tb)
+    return out
+
+
+def loads(ring, off):
+    return ["s_load_dwordx16 s[%d:%d], s[%d:%d], 0x%x" % (ring, ring + 15, SP, SP + 1, off),
+            "s_load_dwordx16 s[%d:%d], s[%d:%d], 0x%x" % (ring + 16, ring + 31, SP, SP + 1, off + 64)]
+
+
+WAIT = "s_waitcnt lgkmcnt(0)"
+
+
+def loop_text(B, groups_per_trip):
+    """groups_per_trip in (2, 4); a trip covers 8*groups_per_trip records = trip_bytes of the record array."""
+    trip = 128 * groups_per_trip
+    pro = ["s_mov_b64 s[%d:%d], %%%d" % (SP, SP + 1, 6 if B == 2 else 12),
+           "s_mov_b64 s[%d:%d], %%%d" % (SE, SE + 1, 7 if B == 2 else 13),
+           "s_mov_b32 s%d, 0x3a83126f" % SEPS,          # softeningSquared = 1e-3f (ver7/GSimulation.cpp:126)
+           "s_mov_b32 s%d, 0x%x" % (SEPS + 1, trip),     # pointer increment, kept in a register: s_add stays 4 bytes
+           "s_nop 4"]
+    pro += loads(RING_A, trip) + [WAIT]                   # group A of the first trip (pointer is biased by -trip)
+    body = []
+    # group 0 (ring A) is resident at the loop head; group g+1 is requested before group g is consumed
+    body += loads(RING_B, trip + 128)
+    body += group_ops(B, RING_A)
+    # four 4-byte instructions together keep the 8-byte alignment of what follows; no scalar load is in flight
+    # while the pointer changes, and SCC (set by the compare) is not written again before the branch
+    body += [WAIT, "s_add_u32 s%d, s%d, s%d" % (SP, SP, SEPS + 1), "s_addc_u32 s%d, s%d, 0" % (SP + 1, SP + 1),
+             "s_cmp_lg_u64 s[%d:%d], s[%d:%d]" % (SP, SP + 1, SE, SE + 1)]
+    # from here on the pointer has advanced by one trip: offsets are relative to the NEW value
+    if groups_per_trip == 2:
+        body += loads(RING_A, trip)                       # next trip's group 0 (over-read on the last trip)
+        body += group_ops(B, RING_B)
+        body += [WAIT, "s_cbranch_scc1 1b"]
+    else:
+        body += loads(RING_A, 256)
+        body += group_ops(B, RING_B)
+        body += [WAIT, "s_nop 0"]
+        body += loads(RING_B, 384)
+        body += group_ops(B, RING_A)
+        body += [WAIT, "s_nop 0"]
+        body += loads(RING_A, trip)
+        body += group_ops(B, RING_B)
+        body += [WAIT, "s_cbranch_scc1 1b"]
+    return pro, body, trip
+
+
+def check_alignment(body):
+    """Every 8-byte instruction must start at a multiple of 8 bytes from the loop head."""
+    off = 0
+    for ins in body:
+        op = ins.split()[0]
+        size = 4 if (op in ("s_waitcnt", "s_add_u32", "s_addc_u32", "s_cmp_lg_u64", "s_cbranch_scc1", "s_nop") or op.endswith("_e32")) else 8
+        assert size == 4 or off % 8 == 0, (ins, off)
+        off += size
+    return off
+
+
+def check_distance(body):
+    """No VALU instruction reads a VGPR written by the instruction just before it (one wait state for trans / packed results)."""
+    import re
+    prev_defs = set()
+    for ins in body:
+        if not ins.startswith("v_"):
+            prev_defs = set()
+            continue
+        ops = ins.split(None, 1)[1]
+        regs = []
+        for m in re.finditer(r"v\[(\d+):(\d+)\]|v(\d+)|%(\d+)", ops):
+            if m.group(1):
+                regs.append(frozenset("v%d" % r for r in range(int(m.group(1)), int(m.group(2)) + 1)))
+            elif m.group(3):
+                regs.append(frozenset(["v%s" % m.group(3)]))
+            else:
+                regs.append(frozenset(["%" + m.group(4)]))
+        dst, srcs = regs[0], regs[1:]
+        for s in srcs:
+            assert not (s & prev_defs), "back-to-back dependency: " + ins
+        prev_defs = set(dst)
+
+
+def emit(B, groups_per_trip):
+    pro, body, trip = loop_text(B, groups_per_trip)
+    nbytes = check_alignment(body)
+    check_distance(body)
+    lines = ['      "%s\\n"' % s for s in pro] + ['      ".p2align 3\\n"', '      "1:\\n"'] + ['      "%s\\n"' % s for s in body]
+    clob = ['"v%d"' % r for r in range(TBASE, TBASE + 24)] + ['"s%d"' % r for r in range(28, 100) if r not in (32, 33)] + ['"scc"', '"memory"']
+    nv = sum(1 for s in body if s.startswith("v_"))
+    ns = len(body) - nv
+    if B == 2:
+        sig = "f32x2 xi, f32x2 yi, f32x2 zi, f32x2& ax, f32x2& ay, f32x2& az"
+        outs = '"+v"(ax), "+v"(ay), "+v"(az)'
+        ins = '"v"(xi), "v"(yi), "v"(zi), "s"(q), "s"(qend)'
+    else:
+        sig = ("f32x2 xi0, f32x2 yi0, f32x2 zi0, f32x2 xi1, f32x2 yi1, f32x2 zi1, f32x2& ax0, f32x2& ay0, f32x2& az0, "
+               "f32x2& ax1, f32x2& ay1, f32x2& az1")
+        outs = '"+v"(ax0), "+v"(ay0), "+v"(az0), "+v"(ax1), "+v"(ay1), "+v"(az1)'
+        ins = '"v"(xi0), "v"(yi0), "v"(zi0), "v"(xi1), "v"(yi1), "v"(zi1), "s"(q), "s"(qend)'
+    txt = []
+    txt.append("// B = %d bodies per lane: %d records per trip, %d VALU + %d scalar instructions, %d bytes of loop body." % (B, trip // 16, nv, ns, nbytes))
+    txt.append("// `first` points at the first record of the j range, `last` one past it; the range is a positive multiple of")
+    txt.append("// kSgprAsmTrip<%d> records.  The final trip requests 8 records past `last` (never used; kSgprOverread spare)." % B)
+    txt.append("template <> constexpr int kSgprAsmTrip<%d> = %d;" % (B, trip // 16))
+    txt.append("__device__ __forceinline__ void sgpr_loop_asm_b%d(const float4* first, const float4* last, %s) {" % (B, sig))
+    txt.append("  const char* q = reinterpret_cast<const char*>(first) - %d;     // biased: all immediate offsets positive" % trip)
+    txt.append("  const char* qend = reinterpret_cast<const char*>(last) - %d;  // value of the pointer after the last trip's advance" % trip)
+    txt.append("  asm volatile(")
+    txt.append("\n".join(lines))
+    txt.append("      : %s" % outs)
+    txt.append("      : %s" % ins)
+    txt.append("      : %s);" % ", ".join(clob))
+    txt.append("}")
+    return "\n".join(txt)
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "nbody-demo-2023_amd", "csrc", "nbx_sgpr_loop.inc")
+    parts = ["// nbx_sgpr_loop.inc -- GENERATED by tools/gen_sgpr_loop.py (see its docstring for the why); do not edit.",
+             "// Included by nbx_kernels.hpp inside namespace nbx.  tests/test_isa_audit.py checks it is in sync with the generator.",
+             "template <int B> constexpr int kSgprAsmTrip = 0;",
+             emit(2, 4), emit(4, 2), ""]
+    open(out, "w").write("\n".join(parts))
+
+
+if __name__ == "__main__":
+    main()
