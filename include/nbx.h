@@ -206,6 +206,32 @@ int nbx_group_download(nbx_group* g, void* pos_x, void* pos_y, void* pos_z, void
 int nbx_group_info(nbx_group* g, int32_t* n_ranks, int32_t* uses_rccl, int32_t rank, nbx_stats_t* rank_stats);
 
 /*
+ * The block partition every multi-rank form uses (host arithmetic only, no GPU needed): block = ceil(n / P) rounded up
+ * to 256 records, rank r owns [r*block, min(n, (r+1)*block)), all ranks hold n_alloc = P*block records.  P = n_ranks
+ * reduced until no rank is empty (*ranks_used); ranks >= P get i_count = 0.  Replaces the reference's
+ * `npp = n / world_size (+ n % world_size on rank 0)` (ver5_all/GSimulation.cpp:99-108), which its slice loops apply
+ * correctly only when n % world_size == 0 (cpu/Compute.cpp:50-51).  Any out pointer may be NULL.
+ */
+int nbx_partition(int32_t n, int32_t n_ranks, int32_t rank, int32_t* ranks_used, int32_t* block, int32_t* i_begin,
+                  int32_t* i_count, int32_t* n_alloc);
+
+/*
+ * One process per GPU (the reference's MPI mode: init_mpi + mpi_bcast_all + mpi_gather_acc,
+ * ver5_all/GSimulation.cpp:93-115,170-214; slices cpu/Compute.cpp:47-58).  Rank 0 obtains a rendezvous token with
+ * nbx_comm_unique_id (ncclGetUniqueId) and ships its NBX_UNIQUE_ID_BYTES bytes to the other ranks by any means (the
+ * drop-in uses a TCP socket, host/rendezvous.hpp); every rank then calls nbx_group_create_rank (ncclCommInitRank) with
+ * the same n / precision / world and its own rank.  The returned group is driven with the nbx_group_* calls above,
+ * which become collective: each process steps its own block, the per-step exchange is one in-place ncclAllGather of the
+ * position blocks, kenergy_out is the same number on every rank (8-byte all-gather, summed in rank order) and
+ * nbx_group_download leaves the full final state on every rank.  `device` < 0 picks rank % device count.  A world
+ * larger than the number of non-empty blocks is refused identically on all ranks.
+ */
+#define NBX_UNIQUE_ID_BYTES 128
+int nbx_comm_unique_id(void* id_out /* NBX_UNIQUE_ID_BYTES bytes */);
+int nbx_group_create_rank(nbx_group** out, int32_t n, int32_t precision, int32_t world, int32_t rank, const void* unique_id,
+                          int32_t device, const nbx_opts* opts);
+
+/*
  * Seed-42 initial conditions of ver7/GSimulation.cpp:45-94, bit-exact and independent of the
  * host's libstdc++: mt19937(42) re-created per array family, libstdc++-11's
  * uniform_real_distribution<float> restated (one 32-bit draw per value).  Host-only (no GPU

@@ -56,19 +56,38 @@ real_type* alloc_array(int n) {
 }  // namespace
 
 GSimulation::GSimulation()
-    : particles(NULL), _kenergy(0), _totTime(0), _totFlops(0), _cpu_ratio(0.f), _thread_dim0(0),
-      _thread_dim1(0), _devices(2), _allocated(false), _alloc_n(0) {
+    : world_rank(0), world_size(1), npp(0), npp_global(NULL), particles(NULL), _kenergy(0), _totTime(0), _totFlops(0),
+      _cpu_ratio(-1.f), _thread_dim0(0), _thread_dim1(0), _devices(0), _allocated(false), _alloc_n(0) {
 #ifndef NBX_BANNER_IN_MAIN  // ver7 prints the banner here (ver7/GSimulation.cpp:26-27), ver5_all in main()
   std::cout << "===============================" << std::endl;
   std::cout << " Initialize Gravity Simulation" << std::endl;
 #endif
   set_npart(2000);
   set_nsteps(500);
-  set_tstep(0.1);
+  // (float)0.1 as in ver7/GSimulation.cpp:30; the fp64 variant (BASELINE.json configs[4]) widens the
+  // float-rounded constants, so its time step is (double)0.1f = 0.100000001490116 -- the value nbx.DT and every fp64
+  // fixture use -- not the double literal 0.1
+  set_tstep(real_type(0.1f));
   set_sfreq(50);
 }
 
-GSimulation::~GSimulation() { release_store(); }
+GSimulation::~GSimulation() {
+  release_store();
+  std::free(npp_global);
+}
+
+// ver5_all/GSimulation.cpp:93-115.  The reference calls MPI_Init here and gives rank 0 the remainder of n / size.
+// This build has no MPI: one process is rank 0 of 1 and owns every body (exactly what the reference's own
+// non-MPI build leaves behind: `world_rank = 0`, :111-113).  Multi-GPU runs inside one process are selected with
+// NBODY_GPUS (start() below), one process per GPU through sharded.py / bench.py.
+void GSimulation::init_mpi() {
+  world_rank = 0;
+  world_size = 1;
+  npp = get_npart();
+  std::free(npp_global);
+  npp_global = static_cast<int*>(std::malloc(sizeof(int)));
+  if (npp_global) npp_global[0] = npp;
+}
 
 void GSimulation::set_number_of_particles(int N) { set_npart(N); }
 void GSimulation::set_number_of_steps(int N) { set_nsteps(N); }
@@ -136,6 +155,18 @@ void GSimulation::start() {
   const int nsteps = get_nsteps();
   const int sfreq = get_sfreq();
   const double dt = (double)get_tstep();
+
+  // ver5_all device word (ver5_all/main.cpp:40-47): 1 = "cpu", 2 = "gpu", 3 = "cpu+gpu", 0 = not given.  libnbx has no
+  // CPU engine by design (no fallback may stand in for the HIP path), so "cpu" is refused here -- also when the
+  // reference's own main.cpp drives this class -- and "cpu+gpu" runs every body on the GPU: the co-execution split of
+  // the OpenCL back end (cpu_ratio, opencl/Compute.cpp:154-162,241-255) is a non-goal, see INTEGRATION.md.
+  if (_devices == 1) {
+    std::cerr << "nbody.x: device \"cpu\" requested, but this build has no CPU engine (the hot path lives in libnbx on the GPU); use gpu"
+              << std::endl;
+    std::exit(1);
+  }
+  if (_devices == 3)
+    std::cerr << "nbody.x: cpu+gpu co-execution is not implemented; all bodies run on the GPU (cpu_ratio ignored)" << std::endl;
 
   init();
   // NBODY_RESTART=<file>: continue from a snapshot instead of the seed-42 initial conditions
@@ -282,7 +313,7 @@ void GSimulation::start() {
       const double pps = (_totTime > 0) ? nd * nd * nsteps / _totTime : 0.0;
       std::fprintf(jf,
                    "{\"n\": %d, \"steps\": %d, \"precision\": %d, \"ranks\": %d, \"exchange\": \"%s\", \"total_time_s\": %.9g, "
-                   "\"pair_per_s_total\": %.9g, \"gflops_avg_reference_convention\": %.9g, \"kenergy_last_printed\": %.9g, "
+                   "\"pair_per_s_total\": %.9g, \"gflops_avg_reference_convention\": %.9g, \"kenergy_last_printed\": %.17g, "
                    "\"kernel\": \"%s\", \"bodies_per_lane\": %d, \"j_split\": %d, \"grid\": [%d, %d], \"device\": \"%s\"}\n",
                    n, nsteps, st.precision, (int)ranks, ranks > 1 ? (rccl ? "rccl" : "copy") : "none", _totTime, pps, av,
                    (double)_kenergy, kernel_name(st.kernel_variant),

@@ -2,8 +2,10 @@
 //   ./nbody_v5.x [nPart [nSteps [cpu|gpu|cpu+gpu [cpu_ratio [dim0 dim1]]]]]
 // Differences from ver7's main: nSteps is read whenever argc > 2, the device word is echoed, and the
 // banner comes from main (compile GSimulation.cpp with -DNBX_BANNER_IN_MAIN).  There is no CPU
-// engine behind libnbx: "cpu" is refused, "cpu+gpu" runs on the GPU alone (cpu_ratio is accepted and
-// ignored); dim0 is the reference's block size (fixed at 256 here), dim1 selects bodies per lane.
+// engine behind libnbx: start() refuses "cpu" and runs "cpu+gpu" on the GPU alone (cpu_ratio is accepted
+// and ignored); dim0 is the reference's block size (fixed at 256 here), dim1 selects bodies per lane.
+// The reference's own ver5_all/main.cpp builds against this class unchanged (tests/test_reference_mains.py);
+// this file differs from it only in reading argv[6] when it exists.
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -26,14 +28,11 @@ int main(int argc, char** argv) {
     if (argc > 5) sim.set_thread_dim0(std::atoi(argv[5]));
     if (argc > 6) sim.set_thread_dim1(std::atoi(argv[6]));
   }
-  if (sim.get_devices() == 1) {
-    std::cerr << "nbody_v5.x: this build has no CPU engine (the hot path lives on the GPU only); use gpu" << std::endl;
-    return 1;
+  sim.init_mpi();
+  if (sim.world_rank == 0) {
+    std::cout << "===============================" << std::endl;
+    std::cout << " Initialize Gravity Simulation" << std::endl;
   }
-  if (sim.get_devices() == 3)
-    std::cerr << "nbody_v5.x: cpu+gpu co-execution is not implemented; running on the GPU alone" << std::endl;
-  std::cout << "===============================" << std::endl;
-  std::cout << " Initialize Gravity Simulation" << std::endl;
   sim.start();
   return 0;
 }

@@ -24,7 +24,7 @@ SYMBOLS = (
     "nbx_step_trace", "nbx_step_local", "nbx_exchange_buffer", "nbx_commit", "nbx_kenergy_partial",
     "nbx_accel", "nbx_sync", "nbx_download", "nbx_ic_pos", "nbx_ic_vel", "nbx_ic_mass", "nbx_profile",
     "nbx_stats", "nbx_group_create", "nbx_group_destroy", "nbx_group_upload", "nbx_group_step", "nbx_group_download",
-    "nbx_group_info",
+    "nbx_group_info", "nbx_partition", "nbx_comm_unique_id", "nbx_group_create_rank",
 )
 
 
@@ -111,6 +111,9 @@ def load():
     L.nbx_group_step.argtypes = [vp, dbl, i32, ctypes.POINTER(dbl)]
     L.nbx_group_download.argtypes = [vp] + [vp] * 6
     L.nbx_group_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), i32, ctypes.POINTER(Stats)]
+    L.nbx_partition.argtypes = [i32, i32, i32] + [ctypes.POINTER(i32)] * 5
+    L.nbx_comm_unique_id.argtypes = [vp]
+    L.nbx_group_create_rank.argtypes = [ctypes.POINTER(vp), i32, i32, i32, i32, vp, i32, ctypes.POINTER(Opts)]
     _lib = L
     return L
 
@@ -287,6 +290,13 @@ class Group:
         P, rccl, st = ctypes.c_int32(), ctypes.c_int32(), Stats()
         _check(self._L.nbx_group_info(self._h, ctypes.byref(P), ctypes.byref(rccl), rank, ctypes.byref(st)), "nbx_group_info")
         return P.value, bool(rccl.value), st.asdict()
+
+
+def partition(n, n_ranks, rank):
+    """nbx_partition: (ranks_used, block, i_begin, i_count, n_alloc) of the library's block partition."""
+    out = [ctypes.c_int32() for _ in range(5)]
+    _check(load().nbx_partition(n, n_ranks, rank, *[ctypes.byref(o) for o in out]), "nbx_partition")
+    return tuple(o.value for o in out)
 
 
 def read_snapshot(path):

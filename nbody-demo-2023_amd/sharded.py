@@ -23,7 +23,8 @@ def block_partition(n, world, rank, align=BLOCK_ALIGN):
     Returns (block, i_begin, i_count, n_alloc).  All ranks hold n_alloc = world*block records;
     records >= n are zero-mass padding (their pair terms are exactly 0).  Unlike the reference's
     slices (cpu/Compute.cpp:50-51, wrong unless n % size == 0) any n works; trailing ranks may
-    own fewer (or zero) real bodies.
+    own fewer real bodies.  A world so large that trailing ranks would own NOTHING is the caller's
+    to refuse (ShardedSimulation does, identically on every rank: see check_world).
     """
     if n <= 0 or world <= 0 or not (0 <= rank < world):
         raise ValueError("bad partition arguments n=%r world=%r rank=%r" % (n, world, rank))
@@ -32,6 +33,22 @@ def block_partition(n, world, rank, align=BLOCK_ALIGN):
     i_begin = min(rank * block, n)
     i_count = max(0, min(n, (rank + 1) * block) - i_begin)
     return block, i_begin, i_count, world * block
+
+
+def check_world(n, world, align=BLOCK_ALIGN):
+    """Raise the SAME ValueError on every rank when `world` ranks cannot all own bodies.
+
+    The partition is a pure function of (n, world), so each rank can decide alone, before any
+    engine or collective exists: nobody is left blocking in an all-gather while another rank has
+    already raised (n = 1500 on 8 ranks: block = 256, ranks 6 and 7 would be empty).  The native
+    nbx_group_create drops empty ranks instead; with one process per rank the launcher fixed the
+    world size, so the only clean answer is to refuse it.
+    """
+    block = block_partition(n, world, 0, align)[0]
+    used = -(-n // block)
+    if used < world:
+        raise ValueError("n=%d bodies fill only %d blocks of %d: a world of %d ranks would leave %d rank(s) without bodies; "
+                         "launch at most %d ranks" % (n, used, block, world, world - used, used))
 
 
 class _DeviceBuffer:
@@ -122,6 +139,7 @@ class ShardedSimulation:
         self.dist = dist if use else None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.rank = self.dist.get_rank() if self.dist else 0
+        check_world(self.n, self.world)  # collective decision: raises on all ranks or on none
         self.block, self.i_begin, self.i_count, self.n_alloc = block_partition(self.n, self.world, self.rank)
         self.rec = 16 if precision == 32 else 32
         factory = engine_factory or NbxEngine

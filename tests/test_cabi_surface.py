@@ -134,3 +134,73 @@ def test_ic_rejects_bad_arguments(nbx):
     assert L.nbx_ic_pos(-1, 32, p, p, p) == nbx.NBX_ERR_ARG
     assert L.nbx_ic_mass(4, 32, None) == nbx.NBX_ERR_ARG
     assert L.nbx_ic_pos(0, 32, p, p, p) == nbx.NBX_OK
+
+
+def test_every_entry_point_rejects_null_and_nonsense_without_aborting(nbx):
+    """each symbol of include/nbx.h called with NULL handles / NULL outputs / out-of-range scalars
+    returns a negative status (never aborts, never throws across the C boundary) and leaves a message."""
+    L = nbx.load()
+    vp, i32 = ctypes.c_void_p, ctypes.c_int32
+    null = vp()
+    h = vp()
+    st = nbx.Stats()
+    d = ctypes.c_double()
+    sz = ctypes.c_size_t()
+    buf = (ctypes.c_char * 128)()
+    calls = {
+        "nbx_create": [lambda: L.nbx_create(None, 10, 32, None), lambda: L.nbx_create(ctypes.byref(h), 0, 32, None),
+                       lambda: L.nbx_create(ctypes.byref(h), -5, 32, None), lambda: L.nbx_create(ctypes.byref(h), 10, 16, None)],
+        "nbx_upload": [lambda: L.nbx_upload(null, *([null] * 7))],
+        "nbx_step": [lambda: L.nbx_step(null, 0.1, 1, None)],
+        "nbx_step_trace": [lambda: L.nbx_step_trace(null, 0.1, 1, ctypes.byref(d)), lambda: L.nbx_step_trace(null, 0.1, 1, None)],
+        "nbx_step_local": [lambda: L.nbx_step_local(null, 0.1)],
+        "nbx_exchange_buffer": [lambda: L.nbx_exchange_buffer(null, ctypes.byref(h), ctypes.byref(sz), ctypes.byref(sz), ctypes.byref(sz))],
+        "nbx_commit": [lambda: L.nbx_commit(null)],
+        "nbx_kenergy_partial": [lambda: L.nbx_kenergy_partial(null, ctypes.byref(d))],
+        "nbx_accel": [lambda: L.nbx_accel(null, null, null, null)],
+        "nbx_sync": [lambda: L.nbx_sync(null)],
+        "nbx_download": [lambda: L.nbx_download(null, *([null] * 6))],
+        "nbx_ic_pos": [lambda: L.nbx_ic_pos(4, 32, null, null, null), lambda: L.nbx_ic_pos(4, 7, buf, buf, buf)],
+        "nbx_ic_vel": [lambda: L.nbx_ic_vel(4, 32, null, null, null)],
+        "nbx_ic_mass": [lambda: L.nbx_ic_mass(4, 32, null), lambda: L.nbx_ic_mass(-1, 32, buf)],
+        "nbx_profile": [lambda: L.nbx_profile(null, 1)],
+        "nbx_stats": [lambda: L.nbx_stats(null, ctypes.byref(st))],
+        "nbx_group_create": [lambda: L.nbx_group_create(None, 10, 32, 2, None, None), lambda: L.nbx_group_create(ctypes.byref(h), 10, 32, 0, None, None),
+                             lambda: L.nbx_group_create(ctypes.byref(h), 10, 32, 65, None, None), lambda: L.nbx_group_create(ctypes.byref(h), 0, 32, 2, None, None)],
+        "nbx_group_upload": [lambda: L.nbx_group_upload(null, *([null] * 7))],
+        "nbx_group_step": [lambda: L.nbx_group_step(null, 0.1, 1, None)],
+        "nbx_group_download": [lambda: L.nbx_group_download(null, *([null] * 6))],
+        "nbx_group_info": [lambda: L.nbx_group_info(null, None, None, 0, None)],
+        "nbx_partition": [lambda: L.nbx_partition(0, 2, 0, *([None] * 5)), lambda: L.nbx_partition(10, 2, 2, *([None] * 5)),
+                          lambda: L.nbx_partition(10, 0, 0, *([None] * 5))],
+        "nbx_comm_unique_id": [lambda: L.nbx_comm_unique_id(null)],
+        "nbx_group_create_rank": [lambda: L.nbx_group_create_rank(None, 10, 32, 1, 0, buf, -1, None),
+                                  lambda: L.nbx_group_create_rank(ctypes.byref(h), 10, 32, 2, 2, buf, -1, None),
+                                  lambda: L.nbx_group_create_rank(ctypes.byref(h), 10, 32, 1, 0, null, -1, None),
+                                  lambda: L.nbx_group_create_rank(ctypes.byref(h), 300, 32, 3, 0, buf, -1, None)],  # rank 2 would be empty
+    }
+    # the remaining symbols cannot fail: they are exercised for "does not crash on NULL"
+    L.nbx_destroy(null)
+    L.nbx_group_destroy(null)
+    assert L.nbx_abi_version() == 1 and isinstance(L.nbx_last_error(), bytes)
+    assert set(calls) | {"nbx_destroy", "nbx_group_destroy", "nbx_abi_version", "nbx_last_error"} == set(nbx.SYMBOLS)
+    for name, fs in calls.items():
+        for k, f in enumerate(fs):
+            rc = f()
+            assert rc < 0, (name, k, rc)
+            assert L.nbx_last_error(), (name, k)
+    assert not h.value  # no handle was ever produced
+
+
+def test_opts_and_stats_layout_match_what_a_c_compiler_sees(nbx, tmp_path):
+    """The ctypes mirrors in nbx.py against the header itself: sizes and the offsets of the newest fields."""
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nbx.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", '
+                   'sizeof(nbx_opts), sizeof(nbx_stats_t), offsetof(nbx_opts, inner_loop), offsetof(nbx_opts, summation_order), '
+                   'offsetof(nbx_stats_t, inner_loop), offsetof(nbx_stats_t, graph_replays)); return 0; }\n')
+    exe = str(tmp_path / "layout.x")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    got = [int(x) for x in subprocess.check_output([exe], text=True).split()]
+    assert got == [ctypes.sizeof(nbx.Opts), ctypes.sizeof(nbx.Stats), nbx.Opts.inner_loop.offset, nbx.Opts.summation_order.offset,
+                   nbx.Stats.inner_loop.offset, nbx.Stats.graph_replays.offset]
+    assert got[0] == 72  # documented in INTEGRATION.md; reserved[] shrinks when a field is added, the size does not move

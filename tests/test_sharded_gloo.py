@@ -65,3 +65,40 @@ def test_gloo_ranks_reproduce_single_process_trace(oracle, tmp_path, n, world, s
         assert res[r]["ke"] == res[0]["ke"]
         assert res[r]["bytes_gathered"] == steps * (world - 1) * res[r]["block"] * 16
     assert sum(x["i_count"] for x in res) == n
+
+
+def test_world_too_large_for_n_is_refused_on_every_rank(tmp_path):
+    """n = 300 on 3 ranks gives blocks of 256 -> rank 2 would own nothing.  All ranks must raise the same error
+    before any engine or collective exists; the run ends promptly instead of hanging in an all-gather."""
+    out = str(tmp_path / "res")
+    port = str(_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(ROOT, "tests", "_dist_worker.py"), "300", "2", out]
+    subprocess.run(cmd, env=env, check=True, timeout=120, capture_output=True)
+    res = [json.load(open("%s.%d" % (out, r))) for r in range(3)]
+    assert all("refused" in r for r in res) and len({r["refused"] for r in res}) == 1
+    assert "at most 2 ranks" in res[0]["refused"]
+
+
+def test_check_world_matches_the_native_partition(nbx):
+    """sharded.check_world / block_partition against libnbx's nbx_partition (the arithmetic nbx_group_create and
+    nbx_group_create_rank use): same block, same slices, and the same verdict on which world sizes leave a rank empty."""
+    import sharded
+    for n in (1, 5, 255, 256, 257, 300, 1500, 2000, 4099, 16384, 262144, 1048576, 1000003):
+        for world in (1, 2, 3, 4, 5, 7, 8, 16, 64):
+            used = nbx.partition(n, world, 0)[0]
+            try:
+                sharded.check_world(n, world)
+                assert used == world, (n, world, used)
+            except ValueError:
+                assert used < world, (n, world, used)
+                continue
+            for r in range(world):
+                u, block, ib, ic, n_alloc = nbx.partition(n, world, r)
+                assert (block, ib, ic, n_alloc) == sharded.block_partition(n, world, r), (n, world, r)
+            # when ranks are dropped the native partition re-balances over the ranks that remain
+        for world in (3, 8):
+            used, block, _, _, n_alloc = nbx.partition(n, world, 0)
+            assert n_alloc == used * block and (used - 1) * block < n <= used * block
+            assert sum(nbx.partition(n, world, r)[3] for r in range(world)) == n
