@@ -311,11 +311,14 @@ void GSimulation::start() {
   if (const char* jp = std::getenv("NBODY_JSON")) {
     if (FILE* jf = std::fopen(jp, "w")) {
       const double pps = (_totTime > 0) ? nd * nd * nsteps / _totTime : 0.0;
+      char avtxt[40];  // fewer than three print windows: the reference's average is nan (nf - 2 <= 0), JSON has no nan
+      if (std::isfinite(av)) std::snprintf(avtxt, sizeof avtxt, "%.9g", av);
+      else std::snprintf(avtxt, sizeof avtxt, "null");
       std::fprintf(jf,
                    "{\"n\": %d, \"steps\": %d, \"precision\": %d, \"ranks\": %d, \"exchange\": \"%s\", \"total_time_s\": %.9g, "
-                   "\"pair_per_s_total\": %.9g, \"gflops_avg_reference_convention\": %.9g, \"kenergy_last_printed\": %.17g, "
+                   "\"pair_per_s_total\": %.9g, \"gflops_avg_reference_convention\": %s, \"kenergy_last_printed\": %.17g, "
                    "\"kernel\": \"%s\", \"bodies_per_lane\": %d, \"j_split\": %d, \"grid\": [%d, %d], \"device\": \"%s\"}\n",
-                   n, nsteps, st.precision, (int)ranks, ranks > 1 ? (rccl ? "rccl" : "copy") : "none", _totTime, pps, av,
+                   n, nsteps, st.precision, (int)ranks, ranks > 1 ? (rccl ? "rccl" : "copy") : "none", _totTime, pps, avtxt,
                    (double)_kenergy, kernel_name(st.kernel_variant),
                    st.bodies_per_lane, st.j_split, st.force_grid_x, st.force_grid_y, st.device_name);
       std::fclose(jf);
