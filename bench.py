@@ -55,7 +55,7 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(kind, n_gpu, precision):
+def cpu_baseline(kind, n_gpu, precision, build="pinned"):
     """The reference's CPU path timed on this box's host cores, on a bounded sample.
 
     kind "reference": oracle/_ref/ver7_trace.x = the reference's unmodified ver7 source compiled in the
@@ -71,7 +71,7 @@ def cpu_baseline(kind, n_gpu, precision):
     while n_cpu > 16384 and steps * float(n_cpu) ** 2 / rate_guess > 25.0:
         n_cpu //= 2
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="spread", OMP_PLACES="threads")
-    exe = os.path.join(ROOT, "oracle", "_ref", "ver7_trace.x" if precision == 32 else "ver7_trace_f64.x")
+    exe = os.path.join(ROOT, "oracle", "_ref", ("ver7_trace_o3.x" if build == "o3" else "ver7_trace.x") if precision == 32 else "ver7_trace_f64.x")
     under_profiler = any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY"))
     if kind == "auto":
         kind = "reference" if (os.path.exists(exe) and not under_profiler) else "port"
@@ -82,7 +82,8 @@ def cpu_baseline(kind, n_gpu, precision):
                            stdout=subprocess.DEVNULL)
             secs = json.load(open(out))["step_seconds"]
         t = statistics.median(secs[1:]) if len(secs) > 1 else secs[0]
-        what = "reference ver7 (unmodified source, g++ -O2 -fopenmp, built in the build container)"
+        what = ("reference ver7 (unmodified source, g++ -O3 -march=x86-64-v3 -fopenmp: best-effort flags, FMA contraction on)" if build == "o3" else
+                "reference ver7 (unmodified source, g++ -O2 -fopenmp, built in the build container)")
     else:
         os.environ.setdefault("OMP_NUM_THREADS", str(threads))  # no OMP_PROC_BIND here: it would pin THIS process
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -151,9 +152,12 @@ def main():
                 "nPart=%d" % n)
 
     # CPU baseline first: it may start a child process, so it runs before this process touches the GPU
-    cpu = None
+    cpu = cpu_o3 = None
     if a.gpus == 1 and rank == 0 and a.cpu_baseline != "none":
         cpu = cpu_baseline(a.cpu_baseline, n, a.precision)
+        # SURVEY.md 8d asks for both builds of the reference: the pinned -O2 one above (the oracle's flags) and a best-effort one
+        if cpu["kind"] == "reference" and a.precision == 32 and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ver7_trace_o3.x")):
+            cpu_o3 = cpu_baseline("reference", n, a.precision, build="o3")
 
     import torch
     import torch.distributed as dist
@@ -206,6 +210,7 @@ def main():
     # N == 1 only: the multi-GPU runs use configs[3]'s n = 1048576; time a few steps of it on this one GPU as
     # well, so that scaling can also be read at equal n (pair/s is nearly flat in n here, see profiles/r01_sweep_*)
     same_n = None
+    rank8 = None
     other_order = None
     if world == 1 and a.order == "auto" and not a.j_split and a.kernel in ("auto",):
         # the same workload with the OTHER summation order (see DESIGN.md "Summation order"): reference order is what
@@ -234,8 +239,31 @@ def main():
         tb = time.perf_counter()
         big.step(3)
         big.sync()
-        same_n = {"n_bodies": 1048576, "steps": 3, "value": 3.0 * 1048576.0 ** 2 / (time.perf_counter() - tb), "unit": "pair/s"}
+        t_big = (time.perf_counter() - tb) / 3.0
+        same_n = {"n_bodies": 1048576, "steps": 3, "value": 1048576.0 ** 2 / t_big, "unit": "pair/s", "ms_per_step": 1e3 * t_big}
         big.close()
+        # what ONE rank of the 8-GPU configuration (configs[3]) computes per step: 131072 owned bodies against all 1048576
+        # resident records, on this GPU.  8-GPU speed-up over one GPU at the same n, before communication and skew, is the
+        # ratio of the two step times (the all-gather is 2 MiB sent / 14 MiB received per rank and step).
+        with nbx.Context(1048576, 32, i_begin=0, i_count=131072, n_alloc=1048576, **opts) as c8:
+            c8.upload(nbx.initial_conditions(1048576, 32))
+            for _ in range(2):
+                c8.step_local(); c8.commit()
+            c8.sync()
+            c8.profile(True)
+            tb = time.perf_counter()
+            for _ in range(6):
+                c8.step_local(); c8.commit()
+            c8.sync()
+            t_rank = (time.perf_counter() - tb) / 6.0
+            st8 = c8.stats()
+        rank8 = {"n_bodies": 1048576, "bodies_owned": 131072, "steps": 6, "ms_per_step": 1e3 * t_rank,
+                 "force_kernel_ms": st8["force_ms_total"] / max(1, st8["force_launches_timed"]),
+                 "roofline_frac": FLOP_PER_PAIR * 131072.0 * 1048576.0 / t_rank / (PEAK_FP32_VECTOR_TFLOPS * 1e12),
+                 "bodies_per_lane": st8["bodies_per_lane"], "grid": [st8["force_grid_x"], st8["force_grid_y"]],
+                 "inner_loop": {1: "cxx", 2: "asm"}.get(st8["inner_loop"], "?"),
+                 "implied_8gpu_speedup_before_communication": t_big / t_rank,
+                 "note": "measured on ONE GPU with a 131072-body slice; not an 8-GPU measurement"}
 
     if rank == 0:
         pairs_per_step = float(n) * float(n)
@@ -243,13 +271,22 @@ def main():
         peak = PEAK_FP32_VECTOR_TFLOPS if a.precision == 32 else PEAK_FP64_VECTOR_TFLOPS
         launch_ms = st["force_ms_total"] / max(1, st["force_launches_timed"])
         achieved = FLOP_PER_PAIR * st["pairs_per_launch"] / (launch_ms * 1e-3) * 1e-12 if launch_ms > 0 else 0.0
-        traffic = None
+        # algorithmic HBM bytes of ONE force launch of the shape that ran: every record once, plus the owned
+        # block's {v,m} read, {v,m} and new position written when the kernel integrates itself (row epilogue), or the S
+        # partial-acceleration slabs when a separate integrate kernel follows
+        rec = 16 if a.precision == 32 else 32
+        own = st["i_count"]
+        alg_bytes = float(rec) * n + (3.0 * rec * own if st["fused_epilogue"] == 1 else float(rec) * own * st["j_split"])
+        traffic = traffic_x1 = None
+        traffic_shape = None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("n") == n and tj.get("gpus", 1) == a.gpus and tj.get("precision", 32) == a.precision:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_x1 = tj.get("hbm_bytes_per_launch_fetch_x1")
+                    traffic_shape = tj.get("profiled_shape")
             except Exception:
                 traffic = None
         line = {
@@ -265,11 +302,18 @@ def main():
                        "bodies_per_lane": st["bodies_per_lane"], "j_split": st["j_split"],
                        "summation_order": {1: "reference", 2: "tree"}.get(st["summation_order"], "?"),
                        "kernel": {1: "lds", 2: "sgpr", 3: "sgprw", 4: "exact"}.get(st["kernel_variant"], "?"),
+                       "inner_loop": {1: "compiler-scheduled", 2: "hand-scheduled asm"}.get(st["inner_loop"], "?"),
                        "grid": [st["force_grid_x"], st["force_grid_y"]], "block": st["force_block"]},
             "gflops_reference_convention": 1e-9 * (29.0 * pairs_per_step + 19.0 * n) * a.steps / elapsed,
             "kenergy_after_run": ke,
             "roofline": {"bound": "valu", "kernel": "nbx::force_kernel", "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         # PMC passes of scripts/profile.sh, per launch: `traffic` = 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950
+                         # correction, calibrated for 16-B/lane vector loads: an upper bound for this kernel's scalar loads),
+                         # `traffic_fetch_x1` = FETCH_SIZE + WRITE_SIZE as counted; both far below what 8 TB/s would move
+                         "traffic_fetch_x1": traffic_x1, "traffic_profiled_shape": traffic_shape,
+                         "algorithmic_bytes": alg_bytes, "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                         "algorithmic_GBps": alg_bytes / (launch_ms * 1e-3) * 1e-9 if launch_ms > 0 else None,
                          "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": st["pairs_per_launch"],
                          "launch_ms_avg": launch_ms, "launches_timed": st["force_launches_timed"],
                          "note": "fp%d vector FMA roofline (north_star: FMA/rsqrt-bound, no MFMA); for fp32 the 157.3 "
@@ -280,11 +324,15 @@ def main():
             line["parity"] = parity
         if same_n:
             line["one_gpu_at_multi_gpu_n"] = same_n
+        if rank8:
+            line["one_rank_of_8_at_1m"] = rank8
         if other_order:
             line["other_summation_order"] = other_order
         if cpu:
             line["cpu_baseline"] = cpu
             line["gpu_over_cpu"] = value / cpu["value"]
+        if cpu_o3:
+            line["cpu_baseline_o3"] = cpu_o3
         print(json.dumps(line), flush=True)
 
     sim.close()

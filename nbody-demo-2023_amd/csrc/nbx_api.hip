@@ -180,12 +180,13 @@ int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 // Bodies per lane of the reference-order kernel (one chain per owned body, S = 1).  Its run time is quantised: the
 // ceil(own / (256 B)) workgroups are spread over the CUs, and a launch takes as long as the fullest CU, which holds
-// r = ceil(workgroups / CUs) of them.  Measured on MI355X at n = 1048576 (profiles/r01_reference_order_thresholds.txt), ms for
-// r = 1, 2, 3, ...: B = 1: 30.9, 48.5, 70.5, 91, 111.5 (plain VALU ops);  B = 2: 38.0, 65.5, 96.5;  B = 4: 66, 123 --
-// linear in r after the first workgroup.  Pick the B with the smallest estimate; ties go to the larger B (fewer
-// workgroups stream the j records).  Only the ratios matter, so the table serves every n.
+// r = ceil(workgroups / CUs) of them.  Measured on MI355X at n = 1048576 with the hand-scheduled loop for B = 2 and 4
+// (profiles/r02_reference_order_thresholds.txt), ms for r = 1, 2, 3, ...: B = 1: 33.4, 48.8, 70.7, 91, 112 (plain VALU ops);
+// B = 2: 34.0, 62.3, 93, 124;  B = 4: 58.2, 120 -- linear in r after the first workgroup.  Pick the B with the smallest
+// estimate; ties go to the larger B (fewer workgroups stream the j records).  Only the ratios matter, so the table
+// serves every n.
 int reference_order_bodies_per_lane(int own, int cus, int max_b) {
-  static const struct { int b; double first, next; } kCost[] = {{1, 30.9, 20.0}, {2, 38.0, 28.5}, {4, 66.0, 57.0}};
+  static const struct { int b; double first, next; } kCost[] = {{1, 33.4, 19.6}, {2, 34.0, 29.5}, {4, 58.2, 61.6}};
   int best = 1;
   double best_t = 0.0;
   for (const auto& k : kCost) {

@@ -5,10 +5,18 @@ usage: python tools/roofline_summary.py gpurun_out/prof r01 [n] [gpus] [precisio
 
 HBM-side bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are KiB per dispatch;
 on gfx950 FETCH_SIZE tallies the 128-B requests of wide (16 B/lane) coalesced reads at 64 B, so the
-read side is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  The counters sit on the L2's
-fabric side, so Infinity-Cache hits are included: this is "bytes that left the XCD L2s", an upper
-bound on HBM bytes.
+guide prescribes doubling the read side; WRITE_SIZE is exact for 16-B-per-lane stores.  That x2 is
+calibrated for vector loads: the SGPR kernels fetch their j records with 64-B SCALAR loads, for which
+it does not apply, so BOTH figures are reported (hbm_bytes_per_launch = guide-corrected upper bound,
+hbm_bytes_per_launch_fetch_x1 = raw FETCH_SIZE + WRITE_SIZE).  The counters sit on the L2's fabric
+side, so Infinity-Cache hits are included: this is "bytes that left the XCD L2s", an upper bound on
+HBM bytes.
+
+Algorithmic bytes are computed for the kernel instance that was actually profiled (template arguments
+and grid from the trace), not from a fixed shape: row epilogue (EPI 1) 16n + 48*own,
+slab epilogue (EPI 0/2) 16n + 16*own*S for the force kernel alone (fp64: records twice as large).
 """
+import re
 import collections
 import csv
 import glob
@@ -87,6 +95,20 @@ def main():
         clock_ghz = counters["GRBM_GUI_ACTIVE"] / 8.0 / (durs["pmc_grbm"] * 1e-3) * 1e-9
     pairs = float(n) * float(n) / gpus
     valu_insts = counters.get("SQ_INSTS_VALU")
+    # shape of the profiled instance: force_kernel<T, B, JSRC, EPI, MINW, MATH, WSPLIT, LOOP>
+    own = n // gpus
+    shape = {"bodies_per_lane": None, "epilogue": None, "j_split": None, "wave_split": None, "loop": None}
+    alg_bytes = None
+    m = re.search(r"force_kernel<(\w+), (\d+), (\d+), (\d+), (\d+), (\d+), (\w+)(?:, (\d+))?>", meta.get("Kernel_Name", ""))
+    if m:
+        B, epi, ws = int(m.group(2)), int(m.group(4)), m.group(7) in ("true", "1")
+        wgx = -(-own // ((64 if ws else 256) * B))
+        S = max(1, int(meta.get("Grid_Size", 0)) // (256 * wgx)) if meta.get("Grid_Size") else None
+        shape = {"bodies_per_lane": B, "epilogue": {0: "slab", 1: "row", 2: "last-arriver"}.get(epi), "j_split": S, "wave_split": ws,
+                 "loop": {None: "cxx", "0": "cxx", "1": "asm"}.get(m.group(8), m.group(8))}
+        alg_bytes = float(rec) * n + (3.0 * rec * own if epi == 1 else float(rec) * own * (S or 1))
+    read_x1 = None if fetch_kib is None else fetch_kib * 1024.0
+    traffic_x1 = None if (read_x1 is None or write_bytes is None) else read_x1 + write_bytes
     summary = {
         "tag": tag, "n": n, "gpus": gpus, "kernel": meta.get("Kernel_Name"), "launch": meta,
         "avg_launch_ms_kernel_trace": avg_ms, "avg_launch_ms_pmc_passes": durs,
@@ -94,7 +116,11 @@ def main():
         "hbm_side_read_bytes_per_launch": read_bytes, "hbm_side_write_bytes_per_launch": write_bytes,
         "hbm_bytes_per_launch": traffic,
         "precision": precision,
-        "algorithmic_bytes_per_launch": float(rec) * n + float(rec) * (n / gpus) * 8,
+        "hbm_bytes_per_launch_fetch_x1": traffic_x1,
+        "profiled_shape": shape,
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "traffic_over_algorithmic": None if not (traffic and alg_bytes) else traffic / alg_bytes,
+        "traffic_fetch_x1_over_algorithmic": None if not (traffic_x1 and alg_bytes) else traffic_x1 / alg_bytes,
         "effective_clock_ghz": clock_ghz,
         "valu_wave_insts_per_64_pairs": None if not valu_insts else valu_insts / (pairs / 64.0),
         "valu_busy_fraction": None,
@@ -109,6 +135,7 @@ def main():
     json.dump(summary, open(os.path.join(dst, "%s_roofline_summary.json" % tag), "w"), indent=1)
     if traffic and precision == 32:
         json.dump({"n": n, "gpus": gpus, "precision": precision, "hbm_bytes_per_launch": traffic,
+                   "hbm_bytes_per_launch_fetch_x1": traffic_x1, "algorithmic_bytes_per_launch": alg_bytes, "profiled_shape": shape,
                    "source": "profiles/%s_roofline_summary.json" % tag},
                   open(os.path.join(dst, "roofline_traffic.json"), "w"))
     print(json.dumps(summary, indent=1))
