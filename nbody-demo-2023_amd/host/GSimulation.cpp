@@ -16,6 +16,7 @@
 
 #include "../../include/nbx.h"
 #include "cpu_time.hpp"
+#include "rendezvous.hpp"
 #include "snapshot.hpp"
 
 namespace {
@@ -57,10 +58,14 @@ real_type* alloc_array(int n) {
 
 GSimulation::GSimulation()
     : world_rank(0), world_size(1), npp(0), npp_global(NULL), particles(NULL), _kenergy(0), _totTime(0), _totFlops(0),
-      _cpu_ratio(-1.f), _thread_dim0(0), _thread_dim1(0), _devices(0), _allocated(false), _alloc_n(0) {
+      _cpu_ratio(-1.f), _thread_dim0(0), _thread_dim1(0), _devices(0), _allocated(false), _alloc_n(0), _multiprocess(false),
+      _master_addr("127.0.0.1"), _master_port(29417), _local_rank(-1) {
+  read_world_env();  // no network yet: only who we are, so that rank 0 alone prints (as in ver5_all/main.cpp:58-61)
 #ifndef NBX_BANNER_IN_MAIN  // ver7 prints the banner here (ver7/GSimulation.cpp:26-27), ver5_all in main()
-  std::cout << "===============================" << std::endl;
-  std::cout << " Initialize Gravity Simulation" << std::endl;
+  if (world_rank == 0) {
+    std::cout << "===============================" << std::endl;
+    std::cout << " Initialize Gravity Simulation" << std::endl;
+  }
 #endif
   set_npart(2000);
   set_nsteps(500);
@@ -76,17 +81,43 @@ GSimulation::~GSimulation() {
   std::free(npp_global);
 }
 
-// ver5_all/GSimulation.cpp:93-115.  The reference calls MPI_Init here and gives rank 0 the remainder of n / size.
-// This build has no MPI: one process is rank 0 of 1 and owns every body (exactly what the reference's own
-// non-MPI build leaves behind: `world_rank = 0`, :111-113).  Multi-GPU runs inside one process are selected with
-// NBODY_GPUS (start() below), one process per GPU through sharded.py / bench.py.
+// Who am I?  NBODY_WORLD / NBODY_RANK, or the variables torchrun exports (WORLD_SIZE / RANK / LOCAL_RANK / MASTER_ADDR /
+// MASTER_PORT), so `python -m torch.distributed.run --no-python --nproc-per-node 8 ./nbody.x 1048576 100` works as well as a
+// shell loop.  Absent: one process, rank 0 of 1.
+void GSimulation::read_world_env() {
+  const char* w = std::getenv("NBODY_WORLD");
+  const char* r = std::getenv("NBODY_RANK");
+  if (!w) { w = std::getenv("WORLD_SIZE"); r = std::getenv("RANK"); }
+  world_size = (w && *w) ? std::atoi(w) : 1;
+  world_rank = (r && *r) ? std::atoi(r) : 0;
+  _multiprocess = w && *w;  // NBODY_WORLD=1 still takes the rank-group path (one-rank rehearsal of RCCL)
+  if (world_size < 1 || world_rank < 0 || world_rank >= world_size) {
+    std::cerr << "nbody.x: bad world description (world " << world_size << ", rank " << world_rank << ")" << std::endl;
+    std::exit(1);
+  }
+  const char* a = std::getenv("NBODY_MASTER_ADDR");
+  if (!a) a = std::getenv("MASTER_ADDR");
+  if (a && *a) _master_addr = a;
+  const char* p = std::getenv("NBODY_MASTER_PORT");
+  if (!p) p = std::getenv("MASTER_PORT");
+  if (p && *p) _master_port = std::atoi(p);
+  _local_rank = env_int("LOCAL_RANK", -1);
+}
+
+// ver5_all/GSimulation.cpp:93-115.  The reference calls MPI_Init here and gives every rank n / size bodies (rank 0 the
+// remainder as well).  Here: the environment says who we are (read_world_env), and the shares are the 256-aligned blocks
+// of nbx_partition -- what each rank's GPU will own.  No network is touched before start().
 void GSimulation::init_mpi() {
-  world_rank = 0;
-  world_size = 1;
-  npp = get_npart();
+  read_world_env();
   std::free(npp_global);
-  npp_global = static_cast<int*>(std::malloc(sizeof(int)));
-  if (npp_global) npp_global[0] = npp;
+  npp_global = static_cast<int*>(std::malloc(sizeof(int) * (size_t)world_size));
+  npp = 0;
+  for (int r = 0; r < world_size && npp_global; ++r) {
+    int32_t cnt = 0;
+    if (get_npart() > 0 && nbx_partition(get_npart(), world_size, r, NULL, NULL, NULL, &cnt, NULL)) die_nbx("nbx_partition");
+    npp_global[r] = cnt;
+    if (r == world_rank) npp = cnt;
+  }
 }
 
 void GSimulation::set_number_of_particles(int N) { set_npart(N); }
@@ -140,6 +171,7 @@ void GSimulation::init() {
 }
 
 void GSimulation::print_header() {
+  if (world_rank != 0) return;  // ver5_all/GSimulation.cpp:119
   std::cout << " nPart = " << get_npart() << "; "
             << "nSteps = " << get_nsteps() << "; "
             << "dt = " << get_tstep() << std::endl;
@@ -165,8 +197,9 @@ void GSimulation::start() {
               << std::endl;
     std::exit(1);
   }
-  if (_devices == 3)
+  if (_devices == 3 && world_rank == 0)
     std::cerr << "nbody.x: cpu+gpu co-execution is not implemented; all bodies run on the GPU (cpu_ratio ignored)" << std::endl;
+  const bool root = world_rank == 0;  // every rank computes; rank 0 alone prints (ver5_all/GSimulation.cpp:119,136,162)
 
   init();
   // NBODY_RESTART=<file>: continue from a snapshot instead of the seed-42 initial conditions
@@ -181,6 +214,7 @@ void GSimulation::start() {
   print_header();
 
   if (n <= 0) {  // the reference would run zero-trip loops; nothing to hand to the GPU
+    if (!root) return;
     std::cout << std::endl << "# Number Threads     : 1" << std::endl;
     std::cout << "# Total Time (s)     : 0" << std::endl;
     std::cout << "# Average Perfomance : " << std::nan("") << " +- " << std::nan("") << std::endl;
@@ -212,7 +246,35 @@ void GSimulation::start() {
   const int gpus = env_int("NBODY_GPUS", 1);
   nbx_ctx* ctx = NULL;
   nbx_group* grp = NULL;
-  if (gpus > 1 || std::getenv("NBX_EXCHANGE")) {
+  if (_multiprocess) {
+    // One process per GPU (the reference's MPI mode, ver5_all/GSimulation.cpp:93-115 + cpu/Compute.cpp:47-58): every
+    // rank has drawn the same seed-42 particles above, so nothing needs broadcasting (the reference re-broadcasts nine
+    // arrays every step); rank 0's communicator token travels over one TCP round (rendezvous.hpp), then RCCL carries the
+    // per-step all-gather.  A world too large for n is refused by every rank before any network is touched.
+    int32_t used = 0;
+    if (nbx_partition(n, world_size, world_rank, &used, NULL, NULL, NULL, NULL)) die_nbx("nbx_partition");
+    if (used != world_size) {
+      std::cerr << "nbody.x: " << n << " bodies fill only " << used << " blocks of 256-aligned size; start at most that many ranks (world is "
+                << world_size << ")" << std::endl;
+      std::exit(1);
+    }
+    char token[NBX_UNIQUE_ID_BYTES];
+    std::memset(token, 0, sizeof token);
+    const bool token_ok = !root || nbx_comm_unique_id(token) == NBX_OK;
+    if (!token_ok) std::cerr << "nbody.x: nbx_comm_unique_id failed: " << nbx_last_error() << std::endl;
+    const int32_t sig[3] = {n, nsteps, kPrecisionBits};
+    std::string rerr;
+    if (!nbx_rendezvous::exchange(world_rank, world_size, _master_addr, _master_port, sig, token, env_int("NBODY_RENDEZVOUS_TIMEOUT", 120), &rerr,
+                                  token_ok)) {
+      std::cerr << "nbody.x: rendezvous failed: " << rerr << std::endl;
+      std::exit(1);
+    }
+    const int dev = opts.device >= 0 ? opts.device : _local_rank;  // NBODY_DEVICE, else LOCAL_RANK, else rank % device count
+    if (nbx_group_create_rank(&grp, n, kPrecisionBits, world_size, world_rank, token, dev, &opts)) die_nbx("nbx_group_create_rank");
+    if (nbx_group_upload(grp, particles->pos_x, particles->pos_y, particles->pos_z, particles->vel_x, particles->vel_y,
+                         particles->vel_z, particles->mass))
+      die_nbx("nbx_group_upload");
+  } else if (gpus > 1 || std::getenv("NBX_EXCHANGE")) {
     if (nbx_group_create(&grp, n, kPrecisionBits, gpus, NULL, &opts)) die_nbx("nbx_group_create");
     if (nbx_group_upload(grp, particles->pos_x, particles->pos_y, particles->pos_z, particles->vel_x, particles->vel_y,
                          particles->vel_z, particles->mass))
@@ -251,7 +313,8 @@ void GSimulation::start() {
     _kenergy = (real_type)ke;
     nf += 1;
     const double wt = w1 - w0;
-    std::cout << " " << std::left << std::setw(8) << done << std::left << std::setprecision(5) << std::setw(8)
+    if (root)
+      std::cout << " " << std::left << std::setw(8) << done << std::left << std::setprecision(5) << std::setw(8)
               << done * get_tstep() << std::left << std::setprecision(5) << std::setw(12) << _kenergy << std::left
               << std::setprecision(5) << std::setw(12) << wt << std::left << std::setprecision(5) << std::setw(12)
               << gflops * sfreq / wt << std::endl;
@@ -284,6 +347,7 @@ void GSimulation::start() {
     nbx_destroy(ctx);
   }
   init_acc();
+  if (!root) return;  // the other ranks hold the same final state; rank 0 reports (ver5_all/GSimulation.cpp:162)
   // NBODY_SNAPSHOT=<file>: keep the final state (the reference drops it at exit)
   if (const char* sp = std::getenv("NBODY_SNAPSHOT")) {
     std::string err;
@@ -304,9 +368,9 @@ void GSimulation::start() {
             << ", " << (st.summation_order == NBX_ORDER_REFERENCE ? "reference-order" : "tree") << " sums"
             << ", bodies/lane " << st.bodies_per_lane << ", j-split " << st.j_split << ", grid " << st.force_grid_x << "x"
             << st.force_grid_y << std::endl;
-  if (ranks > 1)
-    std::cout << "# GPUs / ranks       : " << ranks << " x " << st.i_count << " bodies, position all-gather per step over "
-              << (rccl ? "RCCL" : "device-to-device copies") << std::endl;
+  if (ranks > 1 || _multiprocess)
+    std::cout << "# GPUs / ranks       : " << ranks << " x " << st.i_count << " bodies" << (_multiprocess ? " (one process per rank)" : "")
+              << ", position all-gather per step over " << (rccl ? "RCCL" : "device-to-device copies") << std::endl;
   // NBODY_JSON=<file>: the same facts as one machine-readable line (does not touch stdout)
   if (const char* jp = std::getenv("NBODY_JSON")) {
     if (FILE* jf = std::fopen(jp, "w")) {

@@ -42,8 +42,8 @@ class GSimulation {
   int get_devices() { return _devices; }
 
   // ver5_all/GSimulation.hpp:60-65 -- the MPI surface.  One process: rank 0 of 1 owning all bodies.  Several
-  // processes (one per GPU, NBODY_WORLD / NBODY_RANK or torchrun's WORLD_SIZE / RANK in the environment): the
-  // i-block partition of include/nbx.h, see init_mpi() in GSimulation.cpp.
+  // processes (one per GPU; NBODY_WORLD / NBODY_RANK or torchrun's WORLD_SIZE / RANK in the environment): the
+  // i-block partition of nbx_partition (include/nbx.h); see init_mpi() in GSimulation.cpp.  Only rank 0 prints.
   int world_rank;
   int world_size;
   int npp;          // bodies this process owns
@@ -72,6 +72,12 @@ class GSimulation {
 
   bool _allocated;
   int _alloc_n;
+
+  // one process per GPU (init_mpi): where rank 0 listens for the start-up rendezvous, and this process's GPU
+  bool _multiprocess;
+  std::string _master_addr;
+  int _master_port, _local_rank;
+  void read_world_env();
 
   void allocate_store(int n);
   void release_store();

@@ -249,7 +249,10 @@ class Context:
 class Group:
     """One nbx_group: n_ranks contexts driven by this process (multi-GPU; logical ranks when devices repeat)."""
 
-    def __init__(self, n, precision=32, n_ranks=1, devices=None, **opts):
+    def __init__(self, n, precision=32, n_ranks=1, devices=None, rank=None, unique_id=None, device=-1, **opts):
+        """Single process: n_ranks contexts on `devices`.  One process per GPU: pass rank= and unique_id= (the 128 bytes
+        of unique_id() made on rank 0 and shipped to every rank); n_ranks is then the world size and every call on the
+        group is collective (nbx_group_create_rank)."""
         self._L = load()
         self._h = ctypes.c_void_p()
         self.n, self.precision, self.dtype = int(n), int(precision), _dtype(precision)
@@ -257,6 +260,11 @@ class Group:
         o.struct_size = ctypes.sizeof(Opts)
         for k, v in opts.items():
             setattr(o, k, v)
+        if rank is not None:
+            buf = ctypes.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+            _check(self._L.nbx_group_create_rank(ctypes.byref(self._h), self.n, self.precision, n_ranks, rank, buf, device, ctypes.byref(o)),
+                   "nbx_group_create_rank")
+            return
         dev = None if devices is None else (ctypes.c_int32 * len(devices))(*devices)
         _check(self._L.nbx_group_create(ctypes.byref(self._h), self.n, self.precision, n_ranks, dev, ctypes.byref(o)),
                "nbx_group_create")
@@ -290,6 +298,16 @@ class Group:
         P, rccl, st = ctypes.c_int32(), ctypes.c_int32(), Stats()
         _check(self._L.nbx_group_info(self._h, ctypes.byref(P), ctypes.byref(rccl), rank, ctypes.byref(st)), "nbx_group_info")
         return P.value, bool(rccl.value), st.asdict()
+
+
+UNIQUE_ID_BYTES = 128
+
+
+def unique_id():
+    """nbx_comm_unique_id: the rendezvous token rank 0 creates for a one-process-per-GPU group."""
+    buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+    _check(load().nbx_comm_unique_id(buf), "nbx_comm_unique_id")
+    return buf.raw
 
 
 def partition(n, n_ranks, rank):

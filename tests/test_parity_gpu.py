@@ -1094,3 +1094,39 @@ def test_hand_scheduled_loop_is_the_default_where_it_exists(nbx):
         assert c.stats()["inner_loop"] == nbx.LOOP_CXX
     with pytest.raises(nbx.NbxError):
         nbx.Context(4099, 64, inner_loop=nbx.LOOP_ASM)  # no fp64 instance
+
+
+# ---- one process per GPU (nbx_group_create_rank): the only form a 1-GPU box can run is a world of one ------------------
+def test_rank_group_world_of_one_matches_a_plain_context(nbx):
+    """ncclGetUniqueId -> ncclCommInitRank(1 rank) -> per-step in-place ncclAllGather, kenergy all-gather, velocity
+    all-gather at download: every collective of the multi-process mode runs (with one participant) and the results are
+    those of a plain context, bit for bit."""
+    n, steps = 4099, 30
+    ic = nbx.initial_conditions(n)
+    with nbx.Context(n, 32, use_graph=2) as c:
+        c.upload(ic)
+        ke_ref = c.step(steps)
+        ref = c.download()
+    with nbx.Group(n, 32, n_ranks=1, rank=0, unique_id=nbx.unique_id(), device=0) as g:
+        g.upload(ic)
+        ke = g.step(steps)
+        got = g.download()
+        P, rccl, st = g.info(0)
+    assert P == 1 and rccl and st["i_count"] == n
+    assert ke == ke_ref
+    for f in ref:
+        assert np.array_equal(got[f], ref[f]), f
+
+
+def test_cli_one_process_per_gpu_mode_with_a_world_of_one(tmp_path):
+    """NBODY_WORLD=1: nbody.x takes the multi-process path (rendezvous skipped for a single rank, RCCL communicator of one
+    rank, collective energy and download) and prints what the single-process run prints."""
+    import subprocess
+    exe = os.path.join(ROOT, "nbody-demo-2023_amd", "host", "nbody.x")
+    out = str(tmp_path / "w1.json")
+    p = subprocess.run([exe, "2000", "150"], env=dict(os.environ, NBODY_WORLD="1", NBODY_RANK="0", NBODY_JSON=out), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.splitlines()
+    assert [r[2] for r in _rows(lines)] == ["0.1432", "2.4341", "8.1256"]
+    assert any("one process per rank" in ln and "RCCL" in ln for ln in lines)
+    assert json.load(open(out))["exchange"] == "none"  # a single rank: nothing to exchange with

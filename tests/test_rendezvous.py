@@ -1,0 +1,102 @@
+"""Start-up rendezvous of the one-process-per-GPU drop-in (host/rendezvous.hpp) -- CPU only.
+
+The data path of that mode (ncclCommInitRank + all-gathers) needs one GPU per rank and cannot run here; what can be
+checked anywhere is everything before it: the token reaches every rank unchanged, a mis-launched rank is refused instead
+of deadlocking the first collective, nobody waits for ever, and nbody.x refuses a world that leaves a rank without bodies.
+"""
+import os
+import socket
+import subprocess
+import time
+
+import pytest
+
+from conftest import PKG, ROOT
+
+HOST = os.path.join(PKG, "host")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("rdv") / "rendezvous_driver.x")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-I", HOST, os.path.join(ROOT, "tests", "rendezvous_driver.cpp"), "-o", exe, "-lpthread"])
+    return exe
+
+
+def _run(driver, specs):
+    """specs: list of argument lists (one per process); returns [(rc, stdout)] in the same order."""
+    procs = []
+    for k, a in enumerate(specs):
+        if k == 1:
+            time.sleep(0.3)  # rank 0 listens before the others connect in most runs; late listeners are retried anyway
+        procs.append(subprocess.Popen([driver] + [str(x) for x in a], stdout=subprocess.PIPE, text=True))
+    return [(p.wait(timeout=60), p.stdout.read().strip()) for p in procs]
+
+
+def test_token_reaches_every_rank(driver):
+    port = _free_port()
+    want = "ok " + "".join("%02x" % ((i * 7 + 3) & 255) for i in range(128))
+    res = _run(driver, [[r, 4, port, 1000] for r in range(4)])
+    assert all(rc == 0 and out == want for rc, out in res), res
+
+
+def test_ranks_started_before_rank_zero_keep_retrying(driver):
+    port = _free_port()
+    procs = [subprocess.Popen([driver, str(r), "3", str(port), "1000"], stdout=subprocess.PIPE, text=True) for r in (1, 2)]
+    time.sleep(1.0)
+    procs.insert(0, subprocess.Popen([driver, "0", "3", str(port), "1000"], stdout=subprocess.PIPE, text=True))
+    res = [(p.wait(timeout=60), p.stdout.read().strip()) for p in procs]
+    assert all(rc == 0 and out.startswith("ok 030a11") for rc, out in res), res
+
+
+def test_rank_with_another_problem_size_is_refused(driver):
+    port = _free_port()
+    res = _run(driver, [[0, 2, port, 1000, 5], [1, 2, port, 2000, 5]])
+    assert res[0][0] == 1 and "does not belong to this job" in res[0][1]
+    assert res[1][0] == 1 and "refused by rank 0" in res[1][1]
+
+
+def test_missing_rank_times_out_instead_of_hanging(driver):
+    port = _free_port()
+    t0 = time.time()
+    res = _run(driver, [[0, 3, port, 1000, 2], [1, 3, port, 1000, 2]])  # rank 2 never starts
+    assert time.time() - t0 < 30
+    assert res[0][0] == 1 and "timed out waiting for 1 rank" in res[0][1]
+
+
+def test_rank_zero_failure_is_passed_on(driver):
+    port = _free_port()
+    res = _run(driver, [[0, 3, port, 1000, 10, 0], [1, 3, port, 1000, 10], [2, 3, port, 1000, 10]])
+    assert res[0][0] == 1 and all(rc == 1 and "rank 0 could not initialise" in out for rc, out in res[1:]), res
+
+
+def test_nbody_x_refuses_a_world_with_empty_ranks_on_every_rank():
+    exe = os.path.join(HOST, "nbody.x")
+    for rank in range(3):  # 300 bodies = 2 blocks of 256: three ranks cannot all own bodies; no network is touched
+        p = subprocess.run([exe, "300", "10"], env=dict(os.environ, NBODY_WORLD="3", NBODY_RANK=str(rank)), capture_output=True, text=True, timeout=60)
+        assert p.returncode == 1 and "start at most that many ranks" in p.stderr
+        assert ("Initialize Gravity Simulation" in p.stdout) == (rank == 0)  # only rank 0 prints
+
+
+def test_init_mpi_shares_follow_the_native_partition(nbx, tmp_path):
+    """GSimulation::init_mpi() (the ver5_all surface) reports npp / npp_global = the blocks nbx_partition hands the GPUs."""
+    src = tmp_path / "mpi_probe.cpp"
+    src.write_text('#include "GSimulation.hpp"\nint main() { GSimulation sim; sim.set_number_of_particles(4099); sim.init_mpi();\n'
+                   '  std::cout << sim.world_rank << " " << sim.world_size << " " << sim.npp;\n'
+                   '  for (int r = 0; r < sim.world_size; ++r) std::cout << " " << sim.npp_global[r];\n  std::cout << std::endl; return 0; }\n')
+    exe = str(tmp_path / "mpi_probe.x")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-DNBX_BANNER_IN_MAIN", "-I", HOST, str(src), os.path.join(HOST, "GSimulation.cpp"), "-o", exe,
+                           "-L" + PKG, "-lnbx", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+    for world in (1, 3, 8):
+        for rank in (0, world - 1):
+            out = subprocess.check_output([exe], env=dict(os.environ, NBODY_WORLD=str(world), NBODY_RANK=str(rank)), text=True).split()
+            shares = [nbx.partition(4099, world, r)[3] for r in range(world)]
+            assert [int(x) for x in out] == [rank, world, shares[rank]] + shares
