@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--cpu-baseline", default="auto", choices=("auto", "reference", "port", "none"))
     ap.add_argument("--bodies-per-lane", type=int, default=0)
     ap.add_argument("--j-split", type=int, default=0)
-    ap.add_argument("--kernel", default="auto", choices=("auto", "lds", "sgpr", "sgprw"))
+    ap.add_argument("--kernel", default="auto", choices=("auto", "lds", "sgpr", "sgprw", "jlane"))
     ap.add_argument("--order", default="auto", choices=("auto", "reference", "tree"),
                     help="summation order of a body's pair terms (include/nbx.h): reference = the CPU loop's order")
     a = ap.parse_args()
@@ -177,7 +177,7 @@ def main():
         else:
             dist.init_process_group(backend)
     opts = dict(bodies_per_lane=a.bodies_per_lane, j_split=a.j_split, summation_order={"auto": 0, "reference": 1, "tree": 2}[a.order],
-                kernel_variant={"auto": 0, "lds": 1, "sgpr": 2, "sgprw": 3}[a.kernel])
+                kernel_variant={"auto": 0, "lds": 1, "sgpr": 2, "sgprw": 3, "jlane": 6}[a.kernel])
 
     parity = parity_probe(nbx, n, a.precision) if (rank == 0 and world == 1) else None
 
@@ -228,7 +228,7 @@ def main():
         st2 = s2.engine.ctx.stats()
         other_order = {"summation_order": {1: "reference", 2: "tree"}[alt], "value": float(n) * n * a.steps / el2, "unit": "pair/s",
                        "roofline_frac": FLOP_PER_PAIR * float(n) * n * a.steps / el2 / ((PEAK_FP32_VECTOR_TFLOPS if a.precision == 32 else PEAK_FP64_VECTOR_TFLOPS) * 1e12),
-                       "kernel": {1: "lds", 2: "sgpr", 3: "sgprw"}.get(st2["kernel_variant"], "?"), "bodies_per_lane": st2["bodies_per_lane"],
+                       "kernel": {1: "lds", 2: "sgpr", 3: "sgprw", 6: "jlane"}.get(st2["kernel_variant"], "?"), "bodies_per_lane": st2["bodies_per_lane"],
                        "j_split": st2["j_split"]}
         s2.close()
     if world == 1 and not a.n and a.precision == 32:
@@ -301,7 +301,7 @@ def main():
                        "parallelism": "i-block x%d" % a.gpus, "j_tile": st["j_tile"],
                        "bodies_per_lane": st["bodies_per_lane"], "j_split": st["j_split"],
                        "summation_order": {1: "reference", 2: "tree"}.get(st["summation_order"], "?"),
-                       "kernel": {1: "lds", 2: "sgpr", 3: "sgprw", 4: "exact"}.get(st["kernel_variant"], "?"),
+                       "kernel": {1: "lds", 2: "sgpr", 3: "sgprw", 4: "exact", 6: "jlane"}.get(st["kernel_variant"], "?"),
                        "inner_loop": {1: "compiler-scheduled", 2: "hand-scheduled asm"}.get(st["inner_loop"], "?"),
                        "grid": [st["force_grid_x"], st["force_grid_y"]], "block": st["force_block"]},
             "gflops_reference_convention": 1e-9 * (29.0 * pairs_per_step + 19.0 * n) * a.steps / elapsed,

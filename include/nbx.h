@@ -50,6 +50,9 @@ enum {
                            one thread per body, j strictly ascending, unfused IEEE multiply/add in the source's
                            association, correctly rounded sqrt and divide, G and m multiplied separately.  Positions
                            and velocities then equal the CPU ver7 run exactly (tests compare CRC-32 of whole arrays) */
+  NBX_KERNEL_JLANE = 6, /* fp32, tree order, launch-bound sizes (auto up to 32768 owned bodies): a wave owns `bodies_per_lane`
+                           (2, 4, 8 or 16) bodies wave-uniformly and its 64 lanes split the j records; lane partials meet in LDS
+                           and the wave integrates its bodies itself -- ONE launch per time step, no slabs, no integrate kernel */
   NBX_KERNEL_EXACT_FMA = 5 /* diagnostic: NBX_KERNEL_EXACT with FMA contraction allowed -- what a -march=native / icpc -xAVX2
                            build of the same reference loop computes.  Used to show how far two builds of the REFERENCE
                            drift apart in the chaotic regime (tools/validate_big.py) */
@@ -74,10 +77,9 @@ typedef struct nbx_opts {
   int32_t bodies_per_lane; /* register blocking of i-bodies: 1,2,4,8; 0 = auto */
   int32_t j_split;         /* workgroups sharing one i-block, each summing a j-range; 0 = auto */
   int32_t kernel_variant;  /* NBX_KERNEL_* */
-  int32_t fused_epilogue;  /* 0 = auto (integrate inside the force kernel only when j_split == 1), 1 = always one
-                              launch per step (with j-splits the last workgroup to arrive at an i-block integrates
-                              it; measured slower than the extra launch on MI355X), 2 = always the separate
-                              integrate kernel */
+  int32_t fused_epilogue;  /* 0 / 1 = integrate inside the force kernel where the shape allows it (j_split == 1 without
+                              wave split, and NBX_KERNEL_JLANE); shapes with j-splits always run the separate integrate
+                              kernel.  2 = always the separate integrate kernel */
   int32_t use_graph;       /* 0 = auto, 1 = replay multi-step windows from a hipGraph, 2 = plain launches */
   int32_t external_stream; /* 0 = own non-blocking stream; 1 = enqueue everything on `stream` (caller-owned) */
   int32_t summation_order; /* how a body's n pair terms are added up:
@@ -102,7 +104,7 @@ typedef struct nbx_opts {
 typedef struct nbx_stats_t {
   int32_t n, n_alloc, i_begin, i_count, precision;
   int32_t bodies_per_lane, j_split, j_tile, kernel_variant;
-  int32_t fused_epilogue;      /* 0 separate integrate kernel, 1 integrated directly (one split), 2 last-arriver */
+  int32_t fused_epilogue;      /* 0 separate integrate kernel, 1 integrated by the force kernel itself */
   int32_t summation_order;     /* NBX_ORDER_REFERENCE or NBX_ORDER_TREE actually in use */
   int32_t force_grid_x, force_grid_y, force_block;
   int32_t cu_count, clock_mhz;

@@ -58,6 +58,8 @@ constexpr int kMaxProfiledLaunches = 8192;
 // NBX_ORDER_AUTO: fp32 sums of more terms than this use the reference's order.  131072 x 500 steps agrees with the
 // reference to 2e-5 in tree order (profiles/r01_validate_orders_n131072_s500.log); 262144 x 200 does not (1.3e-3).
 constexpr int kTreeOrderMaxN = 131072;
+// NBX_KERNEL_AUTO, tree order: contexts that own at most this many bodies step with ONE launch (force_jlane_kernel)
+constexpr int kJlaneMaxOwn = 12288;  // measured cross-over with SGPRW ~13k (profiles/r02_jlane_ab.txt)
 
 }  // namespace
 
@@ -74,7 +76,6 @@ struct nbx_ctx {
   void* velm = nullptr;
   void* accp = nullptr;
   double* ke_part = nullptr;
-  unsigned int* arrive = nullptr;  // EPI_LAST arrival counters, one per i-block
   void* mass_all = nullptr;        // NBX_KERNEL_EXACT only: m of every body (the records carry G*m)
   int ke_parts = 0;       // partials written by the last step
   double* ke_dev = nullptr;  // [ke_cap] reduced sums (sum m v^2)
@@ -109,7 +110,7 @@ void launch_force_t(const ForceArgs<T>& a, dim3 grid, hipStream_t st) {
 
 // does a hand-scheduled (LOOP_ASM) instance exist for this combination?
 template <typename T, int JSRC, int EPI, int MATH, bool WS>
-constexpr bool kHasAsmLoop = sizeof(T) == 4 && JSRC == JSRC_SGPR && MATH == MATH_PACKED && !WS && EPI != EPI_LAST;
+constexpr bool kHasAsmLoop = sizeof(T) == 4 && JSRC == JSRC_SGPR && MATH == MATH_PACKED && !WS;
 
 template <typename T>
 using ForceLauncher = void (*)(const ForceArgs<T>&, dim3, hipStream_t);
@@ -145,7 +146,6 @@ ForceLauncher<T> pick_b(int B, int loop) {
 
 template <typename T, int JSRC, int MATH, bool WS>
 ForceLauncher<T> pick_epi(int B, int epi, int loop) {
-  if (epi == EPI_LAST) return pick_b<T, JSRC, EPI_LAST, MATH, WS>(B, loop);
   if (epi == EPI_ROW) {
     if constexpr (!WS) return pick_b<T, JSRC, EPI_ROW, MATH, WS>(B, loop);
     return nullptr;
@@ -162,7 +162,8 @@ ForceLauncher<T> pick(int B, int variant, int epi, int loop) {
 
 // Does the hand-scheduled loop exist for this shape?  (mirror of kHasAsmLoop for run-time shape decisions)
 bool asm_loop_available(const nbx_ctx* c, int epi) {
-  return c->precision == 32 && c->variant == NBX_KERNEL_SGPR && c->math == MATH_PACKED && (c->B == 2 || c->B == 4) && epi != EPI_LAST;
+  (void)epi;
+  return c->precision == 32 && c->variant == NBX_KERNEL_SGPR && c->math == MATH_PACKED && (c->B == 2 || c->B == 4);
 }
 
 template <typename T>
@@ -223,7 +224,7 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   // bodies this context owns: every rank of a sharded run takes the same decision.
   int order = o.summation_order;
   if (order != NBX_ORDER_REFERENCE && order != NBX_ORDER_TREE) {
-    const bool shape_given = o.j_split > 0 || variant == NBX_KERNEL_SGPRW;
+    const bool shape_given = o.j_split > 0 || variant == NBX_KERNEL_SGPRW || variant == NBX_KERNEL_JLANE;  // tree-only shapes
     if (o.j_split == 1 && variant != NBX_KERNEL_SGPRW) order = NBX_ORDER_REFERENCE;
     // fp64 keeps the tree: its summation noise (~1e-13) is far below the 1e-10 fp64 gate in either order
     else order = (!shape_given && c->precision == 32 && c->n > kTreeOrderMaxN) ? NBX_ORDER_REFERENCE : NBX_ORDER_TREE;
@@ -240,6 +241,20 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
     c->math = (c->precision == 32 && B >= 2) ? MATH_PACKED : MATH_SCALAR;
     c->epi = o.fused_epilogue == 2 ? EPI_SLAB : EPI_ROW;
     c->grid = dim3(ceil_div(c->i_count, kBlock * B), 1);
+    return;
+  }
+  // Launch-bound sizes (fp32): one launch per step with the lanes of a wave splitting j (force_jlane_kernel).  Bodies per
+  // wave: the power of two that gives about one wave per SIMD (1024 waves), between 2 and 16.
+  const bool jlane_auto = variant == NBX_KERNEL_AUTO && c->precision == 32 && o.j_split <= 0 && o.bodies_per_lane == 0 &&
+                          o.fused_epilogue != 2 && c->i_count <= kJlaneMaxOwn;
+  if ((variant == NBX_KERNEL_JLANE && c->precision == 32) || jlane_auto) {
+    int NB = o.bodies_per_lane;
+    if (NB != 2 && NB != 4 && NB != 8 && NB != 16) {
+      NB = 2;
+      while (NB < 16 && ceil_div(c->i_count, NB) > cus * 8) NB *= 2;  // measured: two waves per SIMD beat one (profiles/r02_jlane_ab.txt)
+    }
+    c->B = NB; c->S = 1; c->jps = c->n_alloc; c->math = MATH_PACKED; c->variant = NBX_KERNEL_JLANE; c->epi = EPI_ROW;
+    c->grid = dim3(ceil_div(ceil_div(c->i_count, NB), 4), 1);
     return;
   }
   if (variant != NBX_KERNEL_LDS && variant != NBX_KERNEL_SGPR && variant != NBX_KERNEL_SGPRW) variant = NBX_KERNEL_SGPRW;
@@ -267,13 +282,11 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   c->jps = jps;
   c->math = (c->precision == 32 && B >= 2) ? MATH_PACKED : MATH_SCALAR;
   c->variant = variant;
-  // fused_epilogue: 0 auto, 1 on, 2 off.  A single split integrates directly (EPI_ROW).  With splits, "on" lets the
-  // last workgroup to arrive at an i-block integrate it (EPI_LAST: one launch per step) -- measured SLOWER than the
-  // separate integrate kernel on MI355X (n=2048: 18 us vs 7 + 5 us; n=16384: 77 vs 66 + 5 us: every workgroup pays an
-  // agent-scope release, ~2-6 us, where a kernel boundary costs ~1.5 us), so auto never picks it.
+  // fused_epilogue: 0 auto, 1 on, 2 off.  A single split integrates directly (EPI_ROW); shapes with j-splits always
+  // use the separate integrate kernel (one launch per step for small n is NBX_KERNEL_JLANE's job).
   if (o.fused_epilogue == 2) c->epi = EPI_SLAB;
   else if (S == 1 && variant != NBX_KERNEL_SGPRW) c->epi = EPI_ROW;
-  else c->epi = (o.fused_epilogue == 1) ? EPI_LAST : EPI_SLAB;
+  else c->epi = EPI_SLAB;
   c->grid = dim3(ceil_div(c->i_count, iblk), S);
 }
 
@@ -290,8 +303,8 @@ int enqueue_force(nbx_ctx* c, int epi, double dt) {
     HIP_TRY(hipGetLastError());
     return NBX_OK;
   }
-  ForceLauncher<T> fn = pick_force<T>(c, epi);
-  if (!fn) return fail(NBX_ERR_ARG, "no kernel instance for this bodies_per_lane / precision");
+  ForceLauncher<T> fn = c->variant == NBX_KERNEL_JLANE ? nullptr : pick_force<T>(c, epi);
+  if (!fn && c->variant != NBX_KERNEL_JLANE) return fail(NBX_ERR_ARG, "no kernel instance for this bodies_per_lane / precision");
   ForceArgs<T> a{};
   using T4 = typename V4<T>::type;
   a.posm = (const T4*)c->posm[c->cur];
@@ -299,7 +312,6 @@ int enqueue_force(nbx_ctx* c, int epi, double dt) {
   a.velm = (T4*)c->velm;
   a.posm_next = (T4*)c->posm[c->cur ^ 1];
   a.ke_part = c->ke_part;
-  a.arrive = c->arrive;
   a.i_begin = c->i_begin;
   a.i_count = c->i_count;
   a.own_pad = c->own_pad;
@@ -308,7 +320,21 @@ int enqueue_force(nbx_ctx* c, int epi, double dt) {
   a.dt = (T)dt;
   const bool prof = c->profiling && c->ev_used + 2 <= c->ev.size();
   if (prof) HIP_TRY(hipEventRecord(c->ev[c->ev_used], c->stream));
-  fn(a, c->grid, c->stream);
+  if (c->variant == NBX_KERNEL_JLANE) {
+    if constexpr (sizeof(T) == 4) {
+      const int acc_only = epi == EPI_SLAB ? 1 : 0;  // nbx_accel asks for the slab form: accelerations only
+      switch (c->B) {  // prefetch depth: enough records in flight to cover an L2 round trip with NB/2 x 56 cycles of work each
+        case 2: hipLaunchKernelGGL((force_jlane_kernel<2, 8>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only); break;
+        case 4: hipLaunchKernelGGL((force_jlane_kernel<4, 8>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only); break;
+        case 8: hipLaunchKernelGGL((force_jlane_kernel<8, 4>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only); break;
+        default: hipLaunchKernelGGL((force_jlane_kernel<16, 4>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only); break;
+      }
+    } else {
+      return fail(NBX_ERR_ARG, "NBX_KERNEL_JLANE exists in fp32 only");
+    }
+  } else {
+    fn(a, c->grid, c->stream);
+  }
   if (prof) {
     HIP_TRY(hipEventRecord(c->ev[c->ev_used + 1], c->stream));
     c->ev_used += 2;
@@ -558,9 +584,7 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
   CREATE_TRY(hipMalloc(&c->accp, c->rec * (size_t)c->own_pad * c->S));
   const int max_parts = std::max(ceil_div(c->i_count, kBlock), (int)c->grid.x);
   CREATE_TRY(hipMalloc(&c->ke_part, sizeof(double) * (size_t)max_parts));
-  CREATE_TRY(hipMalloc(&c->arrive, sizeof(unsigned int) * (size_t)max_parts));
   if (c->variant == NBX_KERNEL_EXACT || c->variant == NBX_KERNEL_EXACT_FMA) CREATE_TRY(hipMalloc(&c->mass_all, (c->rec / 4) * (size_t)c->n_alloc));
-  CREATE_TRY(hipMemsetAsync(c->arrive, 0, sizeof(unsigned int) * (size_t)max_parts, c->stream));
   CREATE_TRY(hipMemsetAsync(c->posm[0], 0, pos_bytes, c->stream));
   CREATE_TRY(hipMemsetAsync(c->posm[1], 0, pos_bytes, c->stream));
   CREATE_TRY(hipMemsetAsync(c->ke_part, 0, sizeof(double) * (size_t)max_parts, c->stream));
@@ -585,7 +609,6 @@ void nbx_destroy(nbx_ctx* c) {
   if (c->velm) (void)hipFree(c->velm);
   if (c->accp) (void)hipFree(c->accp);
   if (c->ke_part) (void)hipFree(c->ke_part);
-  if (c->arrive) (void)hipFree(c->arrive);
   if (c->mass_all) (void)hipFree(c->mass_all);
   if (c->ke_dev) (void)hipFree(c->ke_dev);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -605,8 +628,6 @@ int nbx_upload(nbx_ctx* c, const void* px, const void* py, const void* pz, const
            : upload_t<double>(c, (const double*)px, (const double*)py, (const double*)pz, (const double*)vx,
                               (const double*)vy, (const double*)vz, (const double*)m);
   if (rc) return rc;
-  HIP_TRY(hipMemsetAsync(c->arrive, 0, sizeof(unsigned int) * (size_t)std::max(ceil_div(c->i_count, kBlock), (int)c->grid.x), c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
   c->cur = 0;
   c->uploaded = true;
   c->pending_commit = false;

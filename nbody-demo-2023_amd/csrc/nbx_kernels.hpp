@@ -143,11 +143,10 @@ __device__ __forceinline__ T euler_update(T ax, T ay, T az, T dt, typename V4<T>
 template <typename T>
 struct ForceArgs {
   const typename V4<T>::type* posm;  // current positions, n_alloc records
-  typename V4<T>::type* accp;        // [gridDim.y][own_pad] partial-acceleration slabs (EPI_SLAB, EPI_LAST)
-  typename V4<T>::type* velm;        // EPI_ROW / EPI_LAST: owned velocities, updated in place
-  typename V4<T>::type* posm_next;   // EPI_ROW / EPI_LAST: next position buffer (owned slice written)
-  double* ke_part;                   // EPI_ROW / EPI_LAST: one partial per i-block (blockIdx.x)
-  unsigned int* arrive;              // EPI_LAST: one arrival counter per i-block, zero between launches
+  typename V4<T>::type* accp;        // [gridDim.y][own_pad] partial-acceleration slabs (EPI_SLAB)
+  typename V4<T>::type* velm;        // EPI_ROW: owned velocities, updated in place
+  typename V4<T>::type* posm_next;   // EPI_ROW: next position buffer (owned slice written)
+  double* ke_part;                   // EPI_ROW: one partial per workgroup (blockIdx.x)
   int i_begin, i_count, own_pad;
   int j_per_split;                   // split y covers [y*jps, min((y+1)*jps, n_alloc)); multiple of kTile for the
                                      // LDS source, of 4*kSgprBatch (2*kSgprBatch per wave under WSPLIT) for the SGPR one
@@ -208,10 +207,10 @@ enum : int { LOOP_CXX = 0, LOOP_ASM = 1 };
 // What a workgroup does with its accelerations:
 //   EPI_SLAB  write them to its split's slab (the separate integrate_kernel, or nbx_accel, consumes the slabs)
 //   EPI_ROW   single split (gridDim.y == 1): integrate its bodies directly, no slab
-//   EPI_LAST  write the slab, then the LAST workgroup of the i-block to arrive (agent-scope release / counter /
-//             acquire, guide section 6 G16) sums the slabs in split order and integrates: one launch per time step
-//             with exactly the arithmetic of integrate_kernel, hence the same bits
-enum : int { EPI_SLAB = 0, EPI_ROW = 1, EPI_LAST = 2 };
+// (Round 1 also had a "last arriver integrates" epilogue for split shapes -- agent-scope release / ticket / acquire.  It was
+// bit-equal but slower than the extra launch at every size, and force_jlane_kernel below now gives launch-bound sizes
+// their single launch per step without any inter-workgroup hand-off; it was removed.)
+enum : int { EPI_SLAB = 0, EPI_ROW = 1 };
 
 // The B i-bodies a lane keeps in registers, and how one j record is applied to them.
 template <typename T, int B, int MATH>
@@ -424,54 +423,107 @@ __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> 
     }
   }
 
-  if constexpr (EPI == EPI_LAST) {
-    // Hand-off between the gridDim.y workgroups of this i-block, placement independent (G16): every storing wave
-    // drains its stores, the workgroup meets, ONE lane releases at agent scope (L2 write-back), waits, and takes a
-    // ticket; whoever draws the last ticket acquires (L1 invalidate), waits, and only then -- behind a barrier -- does
-    // the workgroup read the other workgroups' slabs with plain loads.
-    __shared__ int s_last;
-    __shared__ double ksum[4];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler may drop its own wait after buffer_wbl2
-      const unsigned ticket = __hip_atomic_fetch_add(a.arrive + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = (ticket + 1u == gridDim.y) ? 1 : 0;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        a.arrive[blockIdx.x] = 0u;  // ready for the next launch (visible at the kernel boundary)
-      }
-      s_last = last;
-    }
-    __syncthreads();
-    if (s_last) {  // workgroup-uniform
-      constexpr int kPer = WSPLIT ? 1 : B;          // bodies of this i-block per thread
-      const int first = WSPLIT ? blockIdx.x * (64 * B) + t : base;
-      const bool active = WSPLIT ? (t < 64 * B) : true;
-      const int nsplit = gridDim.y;
-      double ke = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// force_jlane_kernel (NBX_KERNEL_JLANE; fp32, tree order, launch-bound sizes): the roles of i and j swapped.
+//   A WAVE owns NB bodies and holds them wave-uniformly (scalar loads -> SGPRs, two bodies per packed op).  Its 64
+//   LANES each walk every 64th j record (lane l: j = l, l + 64, ...), one record per lane in VGPRs, requested D records
+//   (one trip) ahead with coalesced 1-KiB loads.  Every lane ends with a partial sum for each of the NB bodies; a transpose through LDS
+//   (one padded float4 column per body: conflict-free) lets lane t < NB add body t's 64 partials in lane order, and that
+//   lane integrates the body at once (same euler_update as everywhere else) and contributes to the wave's energy partial.
+// One launch per time step: no partial-acceleration slabs, no integrate kernel, no inter-workgroup hand-off -- which is
+// what bounds n <= 16k (a step there was two dependent launches whose fixed costs exceeded the arithmetic: 21 us per
+// step for 0.9 us of pair work at n = 2048).  Parallelism is ceil(own / NB) waves, so NB is chosen to give ~1024 waves
+// (one per SIMD); the inner loop is the same 12 packed + 2 rsq instructions per two pairs as the other kernels.
+// Summation order: j = lane (mod 64) ascending per lane, then lanes 0..63 in order -- a tree, like SGPRW's, so the kernel
+// serves the tree-order range only (n <= 131072).  acc_only != 0: store the accelerations to accp instead
+// of integrating (nbx_accel).
+// ---------------------------------------------------------------------------------------------
+template <int NB, int D>
+__global__ __launch_bounds__(kBlock, 1) void force_jlane_kernel(const ForceArgs<float> a, const int acc_only) {
+  static_assert(NB % 2 == 0 && NB >= 2 && NB <= 16 && D >= 1, "two bodies per packed operation; body state must fit the SGPR file");
+  __shared__ float4 red[4][NB][65];  // [wave][body][lane], one float4 of padding per column: lanes t read 1040 B apart
+  __shared__ double ksum[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
+  const int b0 = wave * NB;
+
+  f32x2 xi[NB / 2], yi[NB / 2], zi[NB / 2], ax[NB / 2], ay[NB / 2], az[NB / 2];
 #pragma unroll
-      for (int k = 0; k < kPer; ++k) {
-        const int li = first + k * kBlock;
-        if (active && li < a.i_count) {
-          T sx = (T)0, sy = (T)0, sz = (T)0;
-          for (int y = 0; y < nsplit; ++y) {  // split order: the same sum as integrate_kernel
-            const T4 q = a.accp[(size_t)y * a.own_pad + li];
-            sx += q.x; sy += q.y; sz += q.z;
-          }
-          T4 p = a.posm[a.i_begin + li];
-          T4 v = a.velm[li];
-          ke += (double)euler_update<T>(sx, sy, sz, a.dt, p, v);
-          a.velm[li] = v;
-          a.posm_next[a.i_begin + li] = p;
-        }
+  for (int b = 0; b < NB; ++b) {
+    int li = b0 + b;
+    li = li < a.i_count ? li : a.i_count - 1;  // waves / bodies past the end shadow the last owned body
+    const float4 p = a.posm[a.i_begin + li];   // wave-uniform index: a scalar load
+    xi[b / 2][b & 1] = p.x; yi[b / 2][b & 1] = p.y; zi[b / 2][b & 1] = p.z;
+    ax[b / 2][b & 1] = 0.f; ay[b / 2][b & 1] = 0.f; az[b / 2][b & 1] = 0.f;
+  }
+
+  // Two register sets of D records ping-pong: the loads of the NEXT D records are issued before the current D are
+  // applied, so a request has D x NB/2 x 56 cycles of arithmetic to land under (one wave per SIMD has no other wave to
+  // hide an L2 round trip behind).  Indices past the end are clamped to the last record and never applied.
+  const float4* pj = a.posm + lane;
+  const int K = a.n_alloc >> 6;  // records per lane; n_alloc is a multiple of 256, so K >= 4
+  const int last = K - 1;
+  float4 ra[D], rb[D];
+  auto request = [&](float4 (&r)[D], int k0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) r[d] = pj[(size_t)64 * (k0 + d < last ? k0 + d : last)];
+  };
+  auto apply = [&](const float4 (&r)[D]) {
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+      for (int p = 0; p < NB / 2; ++p) pair2(r[d].x, r[d].y, r[d].z, r[d].w, xi[p], yi[p], zi[p], ax[p], ay[p], az[p]);
+  };
+  auto apply_some = [&](const float4 (&r)[D], int count) {  // wave-uniform count in [0, D]
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < count) {
+#pragma unroll
+        for (int p = 0; p < NB / 2; ++p) pair2(r[d].x, r[d].y, r[d].z, r[d].w, xi[p], yi[p], zi[p], ax[p], ay[p], az[p]);
       }
-      const double s = block_sum(ke, ksum);
-      if (t == 0) a.ke_part[blockIdx.x] = s;
+  };
+  int k = 0;
+  request(ra, 0);
+  for (; k + 2 * D <= K; k += 2 * D) {
+    request(rb, k + D);
+    apply(ra);
+    request(ra, k + 2 * D);
+    apply(rb);
+  }
+  if (k < K) {  // fewer than 2 D records left: ra holds records k .. k + D - 1
+    request(rb, k + D);
+    apply_some(ra, K - k < D ? K - k : D);
+    apply_some(rb, K - k - D > 0 ? K - k - D : 0);
+  }
+
+  // lane partials -> LDS columns; lane t < NB adds the 64 partials of body t in lane order
+#pragma unroll
+  for (int b = 0; b < NB; ++b) red[w][b][lane] = make_float4(ax[b / 2][b & 1], ay[b / 2][b & 1], az[b / 2][b & 1], 0.f);
+  __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS queue: the reads below see the writes above
+  double ke = 0.0;
+  const int li = b0 + lane;
+  if (lane < NB && li < a.i_count) {
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll 8
+    for (int l = 0; l < 64; ++l) {
+      const float4 q = red[w][lane][l];
+      sx += q.x; sy += q.y; sz += q.z;
+    }
+    if (acc_only) {
+      a.accp[li] = make_float4(sx, sy, sz, 0.f);
+    } else {
+      float4 p = a.posm[a.i_begin + li];
+      float4 v = a.velm[li];
+      ke = (double)euler_update<float>(sx, sy, sz, a.dt, p, v);
+      a.velm[li] = v;
+      a.posm_next[a.i_begin + li] = p;
     }
   }
+  // one energy partial per workgroup, fixed order (wave shuffle tree, then the four waves)
+  const double s = block_sum(ke, ksum);
+  if (threadIdx.x == 0 && !acc_only) a.ke_part[blockIdx.x] = s;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -35,6 +35,7 @@ const char* kernel_name(int variant) {
     case NBX_KERNEL_SGPRW: return "sgprw";
     case NBX_KERNEL_EXACT: return "exact";
     case NBX_KERNEL_EXACT_FMA: return "exact-fma";
+    case NBX_KERNEL_JLANE: return "jlane";
   }
   return "?";
 }
@@ -233,6 +234,7 @@ void GSimulation::start() {
   if (kv && !std::strcmp(kv, "sgpr")) opts.kernel_variant = NBX_KERNEL_SGPR;
   if (kv && !std::strcmp(kv, "lds")) opts.kernel_variant = NBX_KERNEL_LDS;
   if (kv && !std::strcmp(kv, "sgprw")) opts.kernel_variant = NBX_KERNEL_SGPRW;
+  if (kv && !std::strcmp(kv, "jlane")) opts.kernel_variant = NBX_KERNEL_JLANE;
   if (kv && !std::strcmp(kv, "exact")) opts.kernel_variant = NBX_KERNEL_EXACT;  // bit-for-bit the CPU ver7 arithmetic
 
   // NBODY_ORDER=reference|tree: how each body's pair terms are summed (include/nbx.h summation_order); default auto

@@ -29,18 +29,23 @@ def time_steps(n, precision, target_s=1.0, order=0):
         c.sync()
         per = (time.perf_counter() - t0) / 2
         steps = max(5, min(2000, int(target_s / max(per, 1e-6))))
-        c.profile(True)
+        # wall time first, as a user's run sees it (hipGraph replay of the launch-bound sizes is disabled while the
+        # per-launch events of nbx_profile are recorded, so the two measurements are taken separately)
         t0 = time.perf_counter()
         c.step(steps, kenergy=False)
         c.sync()
         wall = time.perf_counter() - t0
+        c.profile(True)
+        c.step(min(steps, 200), kenergy=False)
+        c.sync()
         st = c.stats()
     kms = st["force_ms_total"] / max(1, st["force_launches_timed"])
     return {"n": n, "steps": steps, "us_per_step": 1e6 * wall / steps, "pair_per_s": float(n) * n * steps / wall,
             "roofline_frac": 20.0 * float(n) * n * steps / wall / PEAK[precision],
             "force_kernel_us": 1e3 * kms, "force_kernel_frac": 20.0 * float(n) * n / (kms * 1e-3) / PEAK[precision] if kms else None,
             "bodies_per_lane": st["bodies_per_lane"], "j_split": st["j_split"], "grid": [st["force_grid_x"], st["force_grid_y"]],
-            "kernel": {1: "lds", 2: "sgpr", 3: "sgprw"}[st["kernel_variant"]],
+            "kernel": {1: "lds", 2: "sgpr", 3: "sgprw", 6: "jlane"}[st["kernel_variant"]], "graph_replay": bool(st["use_graph"]),
+            "inner_loop": {1: "cxx", 2: "asm"}.get(st["inner_loop"], "?"),
             "order": {1: "reference", 2: "tree"}[st["summation_order"]]}
 
 
@@ -57,9 +62,10 @@ def main():
     while n <= a.max_n:
         r = time_steps(n, a.precision, order={"auto": 0, "reference": 1, "tree": 2}[a.order])
         rows.append(r)
-        print("%9d %8d %12.1f %14.1f %9.2f %12.1f %9.2f  %s %s B%d S%d %dx%d" % (
+        print("%9d %8d %12.1f %14.1f %9.2f %12.1f %9.2f  %s %s%s B%d S%d %dx%d" % (
             r["n"], r["steps"], r["us_per_step"], r["pair_per_s"] * 1e-9, 100 * r["roofline_frac"], r["force_kernel_us"],
-            100 * (r["force_kernel_frac"] or 0), r["order"], r["kernel"], r["bodies_per_lane"], r["j_split"], r["grid"][0], r["grid"][1]), flush=True)
+            100 * (r["force_kernel_frac"] or 0), r["order"], r["kernel"], "/asm" if r["inner_loop"] == "asm" else "", r["bodies_per_lane"], r["j_split"],
+            r["grid"][0], r["grid"][1]), flush=True)
         n *= 2
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump({"precision": a.precision, "peak_flops": PEAK[a.precision], "flop_per_pair": 20, "rows": rows}, open(a.out, "w"), indent=1)

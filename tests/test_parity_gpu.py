@@ -87,45 +87,62 @@ def test_fused_and_split_steps_agree(nbx):
     assert np.array_equal(traces[0], traces[1])
 
 
-@pytest.mark.parametrize("n,steps", [(2000, 300), (4099, 120), (16384, 60), (65536, 12), (300, 400)])
-@pytest.mark.parametrize("variant", [1, 2, 3])
-def test_last_arriver_epilogue_is_bit_equal_to_integrate_kernel(nbx, n, steps, variant):
-    """fused_epilogue=1 with j-splits: the last workgroup to reach an i-block sums the slabs and integrates (agent-scope
-    release / ticket / acquire).  A stale slab read would change bits; run many steps, every variant, fp32 and fp64 sizes."""
+# ---- one launch per step for launch-bound sizes: a wave owns NB bodies, its lanes split j (NBX_KERNEL_JLANE) ----------
+@pytest.mark.parametrize("NB", [2, 4, 8, 16])
+@pytest.mark.parametrize("n", [1, 5, 63, 64, 65, 255, 257, 1000, 2000, 4099])
+def test_jlane_accelerations_vs_oracle(nbx, oracle, n, NB):
+    ref = _oracle_acc(oracle, n)
+    ax, ay, az, st = _gpu_acc(nbx, n, kernel_variant=nbx.KERNEL_JLANE, bodies_per_lane=NB)
+    assert st["kernel_variant"] == nbx.KERNEL_JLANE and st["bodies_per_lane"] == NB and st["j_split"] == 1
+    assert _acc_err((ax, ay, az), ref) < 1e-5
+
+
+@pytest.mark.parametrize("n,steps,NB", [(2000, 500, 0), (4099, 40, 0), (1000, 100, 16), (65, 20, 4), (5, 20, 2), (8192, 30, 0)])
+def test_jlane_trajectory_matches_the_two_launch_tree_shape_and_the_reference(nbx, n, steps, NB):
+    """force + Euler + energy in one launch: kinetic energy within rounding of the SGPRW + integrate_kernel pair at every step,
+    against the reference's fixture where one exists, bitwise reproducible, and identical under hipGraph replay."""
     ic = nbx.initial_conditions(n)
-    res = []
-    for fe in (1, 2):
-        with nbx.Context(n, 32, fused_epilogue=fe, kernel_variant=variant, use_graph=2) as c:
-            c.upload(ic)
-            ke = c.step_trace(steps)
-            st = c.stats()
-            res.append((ke, c.download(), st))
-    assert res[0][2]["fused_epilogue"] in (1, 2) and res[1][2]["fused_epilogue"] == 0
-    assert res[0][2]["j_split"] == res[1][2]["j_split"]
-    # energies: same terms, but one fp64 partial per i-block instead of one per 256 bodies => last-bit regrouping only
-    assert rel_err(res[0][0], res[1][0]).max() < 1e-13
-    for f in res[0][1]:
-        assert np.array_equal(res[0][1][f], res[1][1][f]), f
+    opts = dict(kernel_variant=nbx.KERNEL_JLANE, bodies_per_lane=NB)
+    with nbx.Context(n, 32, use_graph=2, **opts) as c:
+        c.upload(ic)
+        ke = c.step_trace(steps)
+        fin = c.download()
+        st = c.stats()
+    assert st["kernel_variant"] == nbx.KERNEL_JLANE and st["fused_epilogue"] == 1 and st["force_grid_y"] == 1
+    with nbx.Context(n, 32, kernel_variant=nbx.KERNEL_SGPRW, use_graph=2) as c:
+        c.upload(ic)
+        assert rel_err(ke, c.step_trace(steps)).max() < 5e-6
+    name = "ver7_f32_n%d_s%d.json" % (n, steps)
+    if os.path.exists(os.path.join(ROOT, "tests", "golden", name)):
+        assert rel_err(ke, load_golden(name)["kenergy"]).max() < 1e-5
+    with nbx.Context(n, 32, use_graph=1, **opts) as c:  # replayed from a graph, energy asked once at the end
+        c.upload(ic)
+        ke_last = c.step(steps)
+        fin2 = c.download()
+        assert c.stats()["graph_replays"] > 0 or steps < 4
+    assert ke_last == ke[-1]
+    for f in fin:
+        assert np.array_equal(fin[f], fin2[f]), f
 
 
-def test_last_arriver_epilogue_fp64_and_sharded(nbx):
-    ic = nbx.initial_conditions(4099, 64)
-    out = []
-    for fe in (1, 2):
-        with nbx.Context(4099, 64, fused_epilogue=fe, j_split=5) as c:
-            c.upload(ic)
-            out.append((c.step_trace(50), c.download()))
-    assert rel_err(out[0][0], out[1][0]).max() < 1e-13
-    for f in out[0][1]:
-        assert np.array_equal(out[0][1][f], out[1][1][f]), f
-    with nbx.Group(4099, 32, n_ranks=4, devices=[0] * 4, fused_epilogue=1, j_split=4) as g, \
-            nbx.Group(4099, 32, n_ranks=4, devices=[0] * 4, fused_epilogue=2, j_split=4) as h:
-        g.upload(nbx.initial_conditions(4099))
-        h.upload(nbx.initial_conditions(4099))
-        assert abs(g.step(40) / h.step(40) - 1.0) < 1e-13
-        dg, dh = g.download(), h.download()
-    for f in dg:
-        assert np.array_equal(dg[f], dh[f]), f
+def test_jlane_is_the_default_for_launch_bound_sizes_and_shards_like_the_others(nbx):
+    for n, want in ((2000, nbx.KERNEL_JLANE), (8192, nbx.KERNEL_JLANE), (16384, nbx.KERNEL_SGPRW), (262144, nbx.KERNEL_SGPR)):
+        with nbx.Context(n, 32) as c:
+            assert c.stats()["kernel_variant"] == want, n
+    with nbx.Context(2000, 64) as c:  # fp64 has no such kernel
+        assert c.stats()["kernel_variant"] == nbx.KERNEL_SGPRW
+    # 4 logical ranks of a small system: every rank owns <= 12288 bodies, so every rank steps with one launch; bit-equal to one context
+    n = 4099
+    ic = nbx.initial_conditions(n)
+    with nbx.Context(n, 32, use_graph=2) as c, nbx.Group(n, 32, n_ranks=4, devices=[0] * 4) as g:
+        c.upload(ic)
+        g.upload(ic)
+        assert g.info(1)[2]["kernel_variant"] == nbx.KERNEL_JLANE
+        k1, k2 = c.step(25), g.step(25)
+        d1, d2 = c.download(), g.download()
+    assert abs(k1 / k2 - 1.0) < 1e-13
+    for f in d1:
+        assert np.array_equal(d1[f], d2[f]), f
 
 
 # ---- kinetic-energy traces against the reference's own output -----------------------------------
@@ -567,7 +584,7 @@ def test_cli_json_summary(tmp_path):
     p = subprocess.run([exe, "2000", "200"], env=dict(os.environ, NBODY_JSON=out), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0
     d = json.load(open(out))
-    assert d["n"] == 2000 and d["steps"] == 200 and d["precision"] == 32 and d["ranks"] == 1 and d["kernel"] == "sgprw"
+    assert d["n"] == 2000 and d["steps"] == 200 and d["precision"] == 32 and d["ranks"] == 1 and d["kernel"] == "jlane"
     assert abs(d["kenergy_last_printed"] - 17.877) < 1e-3 and d["pair_per_s_total"] > 1e9
 
 
