@@ -125,6 +125,31 @@ def test_jlane_trajectory_matches_the_two_launch_tree_shape_and_the_reference(nb
         assert np.array_equal(fin[f], fin2[f]), f
 
 
+@pytest.mark.parametrize("name", ["ver7_f32_n4096_s200.json", "ver7_f32_n8192_s200.json", "ver7_f32_n12288_s100.json"])
+def test_jlane_sizes_against_the_reference_binary(nbx, name):
+    """The sizes the one-launch kernel serves by default (NB = 2, 4, 8) against fixtures produced by the reference's own
+    ver7 binary: kinetic energy at every printed step (s % 50 == 0) within the north-star gate of 1e-4, and the exact mode
+    on the reference's bits at the end of the run."""
+    g = load_golden(name)
+    n, steps = g["n"], g["nsteps"]
+    ref = np.array(g["kenergy"])
+    with nbx.Context(n, 32) as c:
+        c.upload(nbx.initial_conditions(n))
+        ke = c.step_trace(steps)
+        assert c.stats()["kernel_variant"] == nbx.KERNEL_JLANE
+    e = rel_err(ke, ref)
+    _dump("parity_jlane_%s" % name, {"max": float(e.max()), "printed": {str(k): float(e[k - 1]) for k in range(50, steps + 1, 50)},
+                                      "all_steps": [float(x) for x in e]})
+    for k in range(50, steps + 1, 50):
+        assert e[k - 1] < 1e-4, (k, e[k - 1])
+    with nbx.Context(n, 32, kernel_variant=nbx.KERNEL_EXACT) as c:
+        c.upload(nbx.initial_conditions(n))
+        c.step(steps, kenergy=False)
+        d = c.download()
+    for f in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z"):
+        assert _crc(d[f]) == g["final"][f]["crc32"], f
+
+
 def test_jlane_is_the_default_for_launch_bound_sizes_and_shards_like_the_others(nbx):
     for n, want in ((2000, nbx.KERNEL_JLANE), (8192, nbx.KERNEL_JLANE), (16384, nbx.KERNEL_SGPRW), (262144, nbx.KERNEL_SGPR)):
         with nbx.Context(n, 32) as c:
