@@ -59,7 +59,9 @@ constexpr int kMaxProfiledLaunches = 8192;
 // reference to 2e-5 in tree order (profiles/r01_validate_orders_n131072_s500.log); 262144 x 200 does not (1.3e-3).
 constexpr int kTreeOrderMaxN = 131072;
 // NBX_KERNEL_AUTO, tree order: contexts that own at most this many bodies step with ONE launch (force_jlane_kernel)
-constexpr int kJlaneMaxOwn = 12288;  // measured cross-over with SGPRW ~13k (profiles/r02_jlane_ab.txt)
+// (12288: 41 us against SGPRW's 48; at 16384 the two tie at 67 us, and SGPRW's summation tree happens to be the one whose
+// chaotic n = 16384 x 500 run stays inside the 1e-4 gate at every printed step: profiles/r02_config1_by_kernel.txt)
+constexpr int kJlaneMaxOwn = 12288;
 
 }  // namespace
 
@@ -250,8 +252,14 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   if ((variant == NBX_KERNEL_JLANE && c->precision == 32) || jlane_auto) {
     int NB = o.bodies_per_lane;
     if (NB != 2 && NB != 4 && NB != 8 && NB != 16) {
-      NB = 2;
-      while (NB < 16 && ceil_div(c->i_count, NB) > cus * 8) NB *= 2;  // measured: two waves per SIMD beat one (profiles/r02_jlane_ab.txt)
+      // A launch lasts as long as the fullest SIMD: ceil(waves / SIMDs) rounds of NB bodies each.  Fewest body-rounds wins;
+      // ties go to the larger NB (fewer waves stream the j records, fewer LDS transposes) -- the measured optimum at every
+      // size from 2048 to 32768 (profiles/r02_jlane_ab.txt: 2048 -> 2, 4096 -> 4, 8192 -> 8, 12288 -> 4, 16384 -> 16).
+      long best = 0;
+      for (int nb = 2; nb <= 16; nb *= 2) {
+        const long cost = (long)ceil_div(ceil_div(c->i_count, nb), cus * 4) * nb;
+        if (best == 0 || cost <= best) { best = cost; NB = nb; }
+      }
     }
     c->B = NB; c->S = 1; c->jps = c->n_alloc; c->math = MATH_PACKED; c->variant = NBX_KERNEL_JLANE; c->epi = EPI_ROW;
     c->grid = dim3(ceil_div(ceil_div(c->i_count, NB), 4), 1);

@@ -99,6 +99,43 @@ __device__ __forceinline__ void pair2(float xj, float yj, float zj, float gmj, f
   az = __builtin_elementwise_fma(dz, s, az);
 }
 
+// pair2() twice, with the two instruction streams interleaved and pinned: (record a on bodies A) and (record b on bodies
+// B), instruction k of the one followed by instruction k of the other, a scheduling barrier after each such couple.  Every
+// result is consumed two or more instructions after it is produced, which is what the gfx940-family VALU needs (one wait
+// state after a transcendental or packed result) -- hipcc left to itself schedules one 14-instruction chain at a time and
+// pads it with ~1.4 s_nop per pair2 (15 % of the issue slots of the jlane loop).  Operations, association and, per
+// accumulator, the order of additions are exactly pair2's.  SAME_ACC: A and B are the same bodies and share accumulators
+// (two j records on one body pair): record a's terms are added before record b's.
+template <bool SAME_ACC>
+__device__ __forceinline__ void pair2_x2(float xa, float ya, float za, float gma, f32x2 xiA, f32x2 yiA, f32x2 ziA, f32x2& axA,
+                                         f32x2& ayA, f32x2& azA, float xb, float yb, float zb, float gmb, f32x2 xiB, f32x2 yiB,
+                                         f32x2 ziB, f32x2& axB, f32x2& ayB, f32x2& azB) {
+#define NBX_PIN() __builtin_amdgcn_sched_barrier(0)
+  const f32x2 e2 = {softening2<float>(), softening2<float>()};
+  const f32x2 dxa = f32x2{xa, xa} - xiA, dxb = f32x2{xb, xb} - xiB; NBX_PIN();
+  const f32x2 dya = f32x2{ya, ya} - yiA, dyb = f32x2{yb, yb} - yiB; NBX_PIN();
+  const f32x2 dza = f32x2{za, za} - ziA, dzb = f32x2{zb, zb} - ziB; NBX_PIN();
+  f32x2 ra = __builtin_elementwise_fma(dza, dza, e2), rb = __builtin_elementwise_fma(dzb, dzb, e2); NBX_PIN();
+  ra = __builtin_elementwise_fma(dya, dya, ra); rb = __builtin_elementwise_fma(dyb, dyb, rb); NBX_PIN();
+  ra = __builtin_elementwise_fma(dxa, dxa, ra); rb = __builtin_elementwise_fma(dxb, dxb, rb); NBX_PIN();
+  f32x2 ia, ib;
+  ia.x = __builtin_amdgcn_rsqf(ra.x); ib.x = __builtin_amdgcn_rsqf(rb.x); NBX_PIN();
+  ia.y = __builtin_amdgcn_rsqf(ra.y); ib.y = __builtin_amdgcn_rsqf(rb.y); NBX_PIN();
+  const f32x2 qa = ia * ia, qb = ib * ib; NBX_PIN();
+  f32x2 sa = f32x2{gma, gma} * ia, sb = f32x2{gmb, gmb} * ib; NBX_PIN();
+  sa = sa * qa; sb = sb * qb; NBX_PIN();
+  if constexpr (SAME_ACC) {  // one set of accumulators: a's three updates, then b's (each waits three instructions for its input)
+    axA = __builtin_elementwise_fma(dxa, sa, axA); ayA = __builtin_elementwise_fma(dya, sa, ayA); NBX_PIN();
+    azA = __builtin_elementwise_fma(dza, sa, azA); axA = __builtin_elementwise_fma(dxb, sb, axA); NBX_PIN();
+    ayA = __builtin_elementwise_fma(dyb, sb, ayA); azA = __builtin_elementwise_fma(dzb, sb, azA); NBX_PIN();
+  } else {
+    axA = __builtin_elementwise_fma(dxa, sa, axA); axB = __builtin_elementwise_fma(dxb, sb, axB); NBX_PIN();
+    ayA = __builtin_elementwise_fma(dya, sa, ayA); ayB = __builtin_elementwise_fma(dyb, sb, ayB); NBX_PIN();
+    azA = __builtin_elementwise_fma(dza, sa, azA); azB = __builtin_elementwise_fma(dzb, sb, azB); NBX_PIN();
+  }
+#undef NBX_PIN
+}
+
 // Separately rounded multiply and add, so the O(n) update rounds exactly like the reference's x86-64 baseline
 // build (no FMA instruction there).  HIP's __fmul_rn / __fadd_rn are plain `*` / `+` and hipcc's
 // default -ffp-contract=fast fuses them (seen in the ISA, caught by the NBX_KERNEL_EXACT bit-equality tests), hence
@@ -158,7 +195,9 @@ enum : int { JSRC_LDS = 1, JSRC_SGPR = 2 };
 // records per scalar-load batch of the SGPR source (one s_load_dwordx16 = 64 B); a split's j range
 // (a quarter of it under WSPLIT) must be a multiple of this
 template <typename T> constexpr int kSgprBatch = 64 / (4 * (int)sizeof(T));
-constexpr int kSgprOverread = 16;  // spare records behind posm[n_alloc): the pipelined loop reads one batch ahead
+// spare records behind posm[n_alloc), zero-filled: the pipelined scalar loop requests one batch (16 records at most) past
+// the end, the jlane kernel one trip of its widest prefetch (8 blocks of 64 records); nothing read there is ever applied
+constexpr int kSgprOverread = 16 + 8 * 64;
 
 // One 64-byte batch of j records held in 16 SGPRs, loaded by an asm s_load_dwordx16 the compiler cannot
 // sink.  load() only requests; wait() is the first point at which the values may be read.
@@ -461,28 +500,44 @@ __global__ __launch_bounds__(kBlock, 1) void force_jlane_kernel(const ForceArgs<
 
   // Two register sets of D records ping-pong: the loads of the NEXT D records are issued before the current D are
   // applied, so a request has D x NB/2 x 56 cycles of arithmetic to land under (one wave per SIMD has no other wave to
-  // hide an L2 round trip behind).  Indices past the end are clamped to the last record and never applied.
+  // hide an L2 round trip behind).  Requests may run up to D blocks past the end of the array (zero-filled spare records,
+  // kSgprOverread); what they return is never applied.
+  static_assert(D <= 8, "the spare records behind the array cover a prefetch of 8 blocks");
   const float4* pj = a.posm + lane;
   const int K = a.n_alloc >> 6;  // records per lane; n_alloc is a multiple of 256, so K >= 4
-  const int last = K - 1;
   float4 ra[D], rb[D];
   auto request = [&](float4 (&r)[D], int k0) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) r[d] = pj[(size_t)64 * (k0 + d < last ? k0 + d : last)];
+    for (int d = 0; d < D; ++d) r[d] = pj[(size_t)64 * (k0 + d)];
+  };
+  // one record on body pairs (p, p + 1), or -- a wave with a single body pair -- two records on that pair: two pinned,
+  // interleaved instruction streams either way (pair2_x2)
+  auto apply_record = [&](const float4& r) {
+    if constexpr (NB >= 4) {
+#pragma unroll
+      for (int p = 0; p < NB / 2; p += 2)
+        pair2_x2<false>(r.x, r.y, r.z, r.w, xi[p], yi[p], zi[p], ax[p], ay[p], az[p], r.x, r.y, r.z, r.w, xi[p + 1], yi[p + 1], zi[p + 1],
+                        ax[p + 1], ay[p + 1], az[p + 1]);
+    } else {
+      pair2(r.x, r.y, r.z, r.w, xi[0], yi[0], zi[0], ax[0], ay[0], az[0]);
+    }
   };
   auto apply = [&](const float4 (&r)[D]) {
+    if constexpr (NB >= 4) {
 #pragma unroll
-    for (int d = 0; d < D; ++d)
+      for (int d = 0; d < D; ++d) apply_record(r[d]);
+    } else {
+      static_assert(NB >= 4 || D % 2 == 0, "a single body pair takes its records two at a time");
 #pragma unroll
-      for (int p = 0; p < NB / 2; ++p) pair2(r[d].x, r[d].y, r[d].z, r[d].w, xi[p], yi[p], zi[p], ax[p], ay[p], az[p]);
+      for (int d = 0; d < D; d += 2)
+        pair2_x2<true>(r[d].x, r[d].y, r[d].z, r[d].w, xi[0], yi[0], zi[0], ax[0], ay[0], az[0], r[d + 1].x, r[d + 1].y, r[d + 1].z,
+                       r[d + 1].w, xi[0], yi[0], zi[0], ax[0], ay[0], az[0]);
+    }
   };
   auto apply_some = [&](const float4 (&r)[D], int count) {  // wave-uniform count in [0, D]
 #pragma unroll
     for (int d = 0; d < D; ++d)
-      if (d < count) {
-#pragma unroll
-        for (int p = 0; p < NB / 2; ++p) pair2(r[d].x, r[d].y, r[d].z, r[d].w, xi[p], yi[p], zi[p], ax[p], ay[p], az[p]);
-      }
+      if (d < count) apply_record(r[d]);
   };
   int k = 0;
   request(ra, 0);
