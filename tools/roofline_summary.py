@@ -104,7 +104,7 @@ def main():
         B, epi, ws = int(m.group(2)), int(m.group(4)), m.group(7) in ("true", "1")
         wgx = -(-own // ((64 if ws else 256) * B))
         S = max(1, int(meta.get("Grid_Size", 0)) // (256 * wgx)) if meta.get("Grid_Size") else None
-        shape = {"bodies_per_lane": B, "epilogue": {0: "slab", 1: "row", 2: "last-arriver"}.get(epi), "j_split": S, "wave_split": ws,
+        shape = {"bodies_per_lane": B, "epilogue": {0: "slab", 1: "row"}.get(epi), "j_split": S, "wave_split": ws,
                  "loop": {None: "cxx", "0": "cxx", "1": "asm"}.get(m.group(8), m.group(8))}
         alg_bytes = float(rec) * n + (3.0 * rec * own if epi == 1 else float(rec) * own * (S or 1))
     read_x1 = None if fetch_kib is None else fetch_kib * 1024.0
