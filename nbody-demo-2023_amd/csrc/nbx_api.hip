@@ -184,12 +184,12 @@ int round_up(int a, int b) { return ceil_div(a, b) * b; }
 // Bodies per lane of the reference-order kernel (one chain per owned body, S = 1).  Its run time is quantised: the
 // ceil(own / (256 B)) workgroups are spread over the CUs, and a launch takes as long as the fullest CU, which holds
 // r = ceil(workgroups / CUs) of them.  Measured on MI355X at n = 1048576 with the hand-scheduled loop for B = 2 and 4
-// (profiles/r02_reference_order_thresholds.txt), ms for r = 1, 2, 3, ...: B = 1: 33.4, 48.8, 70.7, 91, 112 (plain VALU ops);
-// B = 2: 34.0, 62.3, 93, 124;  B = 4: 58.2, 120 -- linear in r after the first workgroup.  Pick the B with the smallest
+// (profiles/r02_reference_order_thresholds.txt), ms for r = 1, 2, 3, ...: B = 1: 31.0, 48.6, 70.3, 91, 112 (plain VALU ops);
+// B = 2: 31.5, 59.6, 88.5, 118;  B = 4: 59.3, 117.4, 175.6, 234.6 -- linear in r after the first workgroup.  Pick the B with the smallest
 // estimate; ties go to the larger B (fewer workgroups stream the j records).  Only the ratios matter, so the table
 // serves every n.
 int reference_order_bodies_per_lane(int own, int cus, int max_b) {
-  static const struct { int b; double first, next; } kCost[] = {{1, 33.4, 19.6}, {2, 34.0, 29.5}, {4, 58.2, 61.6}};
+  static const struct { int b; double first, next; } kCost[] = {{1, 31.0, 20.2}, {2, 31.5, 28.8}, {4, 59.8, 58.2}};
   int best = 1;
   double best_t = 0.0;
   for (const auto& k : kCost) {
@@ -273,7 +273,9 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   if (B == 0) B = c->i_count >= 16384 ? 4 : 2;
   const int iblk = (variant == NBX_KERNEL_SGPRW ? 64 : kBlock) * B;  // bodies per workgroup
   // j-range granularity of one split: a whole LDS tile / two pipelined SGPR batches (per wave)
-  const int gran = variant == NBX_KERNEL_LDS ? kTile : 32;
+  // (the hand-scheduled loop of the plain SGPR kernel walks whole trips of up to 64 records)
+  const int gran = variant == NBX_KERNEL_LDS ? kTile : (variant == NBX_KERNEL_SGPR ? 64 : 32);
+  static_assert(64 % kSgprAsmTrip<2> == 0 && 64 % kSgprAsmTrip<4> == 0 && kTile % 64 == 0, "j ranges are whole trips of the asm loop");
   const int max_split = std::max(1, c->n_alloc / gran);
   int S = o.j_split;
   if (S <= 0) {

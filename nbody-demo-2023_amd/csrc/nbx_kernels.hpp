@@ -349,7 +349,7 @@ __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> 
       cur ^= 1;
     }
   } else if constexpr (LOOP == LOOP_ASM) {
-    // j range = a positive multiple of kSgprAsmTrip<B> records (the host rounds j_per_split to 32; n_alloc is a multiple of 256)
+    // j range = a positive multiple of kSgprAsmTrip<B> records (the host rounds j_per_split to 64; n_alloc is a multiple of 256)
     if (j0 < j1) ib.apply_range_asm(a.posm + j0, a.posm + j1);
   } else {
     // Wave-uniform j index => the records travel by s_load_dwordx16 (64 B = kSgprBatch records) into

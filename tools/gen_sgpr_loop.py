@@ -94,7 +94,8 @@ WAIT = "s_waitcnt lgkmcnt(0)"
 
 
 def loop_text(B, groups_per_trip):
-    """groups_per_trip in (2, 4); a trip covers 8*groups_per_trip records = trip_bytes of the record array."""
+    """groups_per_trip even; a trip covers 8*groups_per_trip records = trip_bytes of the record array."""
+    assert groups_per_trip % 2 == 0 and groups_per_trip >= 2
     trip = 128 * groups_per_trip
     pro = ["s_mov_b64 s[%d:%d], %%%d" % (SP, SP + 1, 6 if B == 2 else 12),
            "s_mov_b64 s[%d:%d], %%%d" % (SE, SE + 1, 7 if B == 2 else 13),
@@ -111,20 +112,12 @@ def loop_text(B, groups_per_trip):
     body += [WAIT, "s_add_u32 s%d, s%d, s%d" % (SP, SP, SEPS + 1), "s_addc_u32 s%d, s%d, 0" % (SP + 1, SP + 1),
              "s_cmp_lg_u64 s[%d:%d], s[%d:%d]" % (SP, SP + 1, SE, SE + 1)]
     # from here on the pointer has advanced by one trip: offsets are relative to the NEW value
-    if groups_per_trip == 2:
-        body += loads(RING_A, trip)                       # next trip's group 0 (over-read on the last trip)
-        body += group_ops(B, RING_B)
-        body += [WAIT, "s_cbranch_scc1 1b"]
-    else:
-        body += loads(RING_A, 256)
-        body += group_ops(B, RING_B)
-        body += [WAIT, "s_nop 0"]
-        body += loads(RING_B, 384)
-        body += group_ops(B, RING_A)
-        body += [WAIT, "s_nop 0"]
-        body += loads(RING_A, trip)
-        body += group_ops(B, RING_B)
-        body += [WAIT, "s_cbranch_scc1 1b"]
+    rings = (RING_A, RING_B)
+    for g in range(1, groups_per_trip):
+        nxt = g + 1
+        body += loads(rings[nxt % 2], trip if nxt == groups_per_trip else 128 * nxt)  # next trip's group 0 is over-read on the last trip
+        body += group_ops(B, rings[g % 2])
+        body += [WAIT, "s_cbranch_scc1 1b" if nxt == groups_per_trip else "s_nop 0"]
     return pro, body, trip
 
 
@@ -202,7 +195,7 @@ def main():
     parts = ["// nbx_sgpr_loop.inc -- GENERATED by tools/gen_sgpr_loop.py (see its docstring for the why); do not edit.",
              "// Included by nbx_kernels.hpp inside namespace nbx.  tests/test_isa_audit.py checks it is in sync with the generator.",
              "template <int B> constexpr int kSgprAsmTrip = 0;",
-             emit(2, 4), emit(4, 2), ""]
+             emit(2, 8), emit(4, 4), ""]
     open(out, "w").write("\n".join(parts))
 
 

@@ -11,7 +11,7 @@ for own in (32768, 65536, 81920, 98304, 131072, 163840, 196608, 262144, 327680, 
         def run(k):
             for _ in range(k):
                 c.step_local(); c.commit()
-        run(1); c.sync(); c.profile(True); run(3); c.sync()
+        run(2); c.sync(); c.profile(True); run(max(3, int(6e11 / (float(n) * own)))); c.sync()
         st = c.stats(); c.close()
         ms = st['force_ms_total'] / st['force_launches_timed']
         row.append("B%d %7.3f ms %5.1f%%" % (B, ms, 100 * 20.0 * float(n) * own / (ms * 1e-3) / 157.3e12))
