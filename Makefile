@@ -9,11 +9,13 @@ all: lib host oracle
 
 lib: $(PKG)/libnbx.so
 
-$(PKG)/nbx_api.o: $(CSRC)/nbx_api.hip $(CSRC)/nbx_kernels.hpp $(CSRC)/nbx_sgpr_loop.inc include/nbx.h
+$(PKG)/nbx_api.o: $(CSRC)/nbx_api.hip $(CSRC)/nbx_internal.hpp $(CSRC)/nbx_kernels.hpp $(CSRC)/nbx_sgpr_loop.inc include/nbx.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(PKG)/nbx_group.o: $(CSRC)/nbx_group.hip $(CSRC)/nbx_internal.hpp include/nbx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(PKG)/nbx_ic.o: $(CSRC)/nbx_ic.cpp include/nbx.h
 	$(HIPCC) -O2 -std=c++17 -fPIC -Wall -ffp-contract=off -c $< -o $@
-$(PKG)/libnbx.so: $(PKG)/nbx_api.o $(PKG)/nbx_ic.o
+$(PKG)/libnbx.so: $(PKG)/nbx_api.o $(PKG)/nbx_group.o $(PKG)/nbx_ic.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -ldl
 
 host: lib

@@ -6,8 +6,6 @@
 // No CPU fallback exists: without a HIP device every entry point fails with NBX_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
-#include <dlfcn.h>
-#include <rccl/rccl.h>  // types and prototypes only: librccl is dlopen'ed (struct Rccl), never linked
 
 #include <algorithm>
 #include <cstdio>
@@ -16,43 +14,23 @@
 #include <exception>
 #include <new>
 #include <string>
-#include <type_traits>
 #include <vector>
 
-#include "../../include/nbx.h"
+#include "nbx_internal.hpp"
 #include "nbx_kernels.hpp"
 
 using namespace nbx;
 
+using namespace nbx_detail;
+
+namespace nbx_detail {
+std::string& last_error() {
+  thread_local std::string err;
+  return err;
+}
+}  // namespace nbx_detail
+
 namespace {
-
-thread_local std::string g_err;
-
-int fail(int code, const std::string& msg) {
-  g_err = msg;
-  return code;
-}
-
-#define HIP_TRY(expr)                                                                          \
-  do {                                                                                         \
-    hipError_t e_ = (expr);                                                                    \
-    if (e_ != hipSuccess)                                                                      \
-      return fail(NBX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));          \
-  } while (0)
-
-// No C++ exception may cross the C boundary: every entry point that can allocate host memory runs inside this.
-template <typename F>
-int guarded(const char* where, F&& body) noexcept {
-  try {
-    return body();
-  } catch (const std::bad_alloc&) {
-    try { return fail(NBX_ERR_ALLOC, std::string(where) + ": out of host memory"); } catch (...) { return NBX_ERR_ALLOC; }
-  } catch (const std::exception& e) {
-    try { return fail(NBX_ERR_STATE, std::string(where) + ": " + e.what()); } catch (...) { return NBX_ERR_STATE; }
-  } catch (...) {
-    return NBX_ERR_STATE;
-  }
-}
 
 constexpr int kMaxProfiledLaunches = 8192;
 // NBX_ORDER_AUTO: fp32 sums of more terms than this use the reference's order.  131072 x 500 steps agrees with the
@@ -64,41 +42,6 @@ constexpr int kTreeOrderMaxN = 131072;
 constexpr int kJlaneMaxOwn = 12288;
 
 }  // namespace
-
-struct nbx_ctx {
-  int n = 0, n_alloc = 0, i_begin = 0, i_count = 0, own_pad = 0, precision = 32;
-  int B = 1, S = 1, jps = 0, variant = NBX_KERNEL_LDS, epi = EPI_SLAB, math = MATH_SCALAR, order = NBX_ORDER_TREE;
-  int loop = LOOP_CXX;  // LOOP_ASM where the hand-scheduled j loop is in use
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  size_t rec = 16;  // bytes per {x,y,z,w} record
-  void* posm[2] = {nullptr, nullptr};
-  int cur = 0;
-  void* velm = nullptr;
-  void* accp = nullptr;
-  double* ke_part = nullptr;
-  void* mass_all = nullptr;        // NBX_KERNEL_EXACT only: m of every body (the records carry G*m)
-  int ke_parts = 0;       // partials written by the last step
-  double* ke_dev = nullptr;  // [ke_cap] reduced sums (sum m v^2)
-  int ke_cap = 0;
-  bool uploaded = false;
-  bool pending_commit = false;
-  long long steps_done = 0;
-  // profiling
-  bool profiling = false;
-  std::vector<hipEvent_t> ev;  // pairs start/stop
-  size_t ev_used = 0;
-  double force_ms_total = 0.0;
-  long long force_timed = 0;
-  hipDeviceProp_t prop{};
-  dim3 grid;
-  // hipGraph replay of multi-step windows (launch-bound small n)
-  bool use_graph = false;
-  struct GraphUnit { int steps; int parity; double dt; hipGraphExec_t exec; };
-  std::vector<GraphUnit> graphs;
-  long long graph_replays = 0;
-};
 
 namespace {
 
@@ -178,8 +121,6 @@ ForceLauncher<T> pick_force(const nbx_ctx* c, int epi) {
   return pick<T, MATH_SCALAR>(c->B, c->variant, epi, loop);
 }
 
-int ceil_div(int a, int b) { return (a + b - 1) / b; }
-int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 // Bodies per lane of the reference-order kernel (one chain per owned body, S = 1).  Its run time is quantised: the
 // ceil(own / (256 B)) workgroups are spread over the CUs, and a launch takes as long as the fullest CU, which holds
@@ -413,12 +354,14 @@ int ensure_ke_cap(nbx_ctx* c, int need) {
   return NBX_OK;
 }
 
-int enqueue_ke_reduce(nbx_ctx* c, int slot) {
+}  // namespace
+int nbx_detail::enqueue_ke_reduce(nbx_ctx* c, int slot) {
   hipLaunchKernelGGL(ke_reduce_kernel, dim3(1), dim3(kBlock), 0, c->stream, (const double*)c->ke_part,
                      c->ke_parts, c->ke_dev + slot);
   HIP_TRY(hipGetLastError());
   return NBX_OK;
 }
+namespace {
 
 int drain_profile(nbx_ctx* c) {
   for (size_t k = 0; k + 1 < c->ev_used; k += 2) {
@@ -431,10 +374,12 @@ int drain_profile(nbx_ctx* c) {
   return NBX_OK;
 }
 
-int use_device(nbx_ctx* c) {
+}  // namespace
+int nbx_detail::use_device(nbx_ctx* c) {
   HIP_TRY(hipSetDevice(c->device));
   return NBX_OK;
 }
+namespace {
 
 template <typename T>
 int upload_t(nbx_ctx* c, const T* px, const T* py, const T* pz, const T* vx, const T* vy, const T* vz,
@@ -514,7 +459,7 @@ int accel_t(nbx_ctx* c, T* ax, T* ay, T* az) {
 
 extern "C" {
 
-const char* nbx_last_error(void) { return g_err.c_str(); }
+const char* nbx_last_error(void) { return last_error().c_str(); }
 int32_t nbx_abi_version(void) { return NBX_ABI_VERSION; }
 
 int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts) {
@@ -603,7 +548,7 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
   if (ensure_ke_cap(c, 64) != NBX_OK) return NBX_ERR_ALLOC;  // message set by ensure_ke_cap
   owner.c = nullptr;
   *out = c;
-  g_err.clear();
+  last_error().clear();
   return NBX_OK;
   });
 }
@@ -866,422 +811,4 @@ int nbx_stats(nbx_ctx* c, nbx_stats_t* s) {
 
 }  // extern "C"
 
-// =============================================================================================
-// nbx_group: single-process multi-GPU driver (see include/nbx.h)
-// =============================================================================================
-namespace {
-
-// The RCCL entry points used, resolved at run time so libnbx.so has no link-time dependency on librccl (and binds to
-// the copy already in the process when a host such as PyTorch brought its own).  Every pointer takes its type from
-// rccl.h's own prototype (decltype), so a signature or enum change in the header is a compile error here, not a
-// silent ABI mismatch at the first multi-GPU run.
-struct Rccl {
-  typedef ncclComm_t comm_t;
-  decltype(&ncclCommInitAll) CommInitAll = nullptr;
-  decltype(&ncclCommInitRank) CommInitRank = nullptr;
-  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-  decltype(&ncclCommDestroy) CommDestroy = nullptr;
-  decltype(&ncclGroupStart) GroupStart = nullptr;
-  decltype(&ncclGroupEnd) GroupEnd = nullptr;
-  decltype(&ncclAllGather) AllGather = nullptr;
-  decltype(&ncclGetErrorString) GetErrorString = nullptr;
-  bool ok = false;
-  template <typename F> static void sym(void* h, const char* name, F& fn) { fn = reinterpret_cast<F>(dlsym(h, name)); }
-  bool load() {
-    if (ok) return true;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return false;
-    sym(h, "ncclCommInitAll", CommInitAll);
-    sym(h, "ncclCommInitRank", CommInitRank);
-    sym(h, "ncclGetUniqueId", GetUniqueId);
-    sym(h, "ncclCommDestroy", CommDestroy);
-    sym(h, "ncclGroupStart", GroupStart);
-    sym(h, "ncclGroupEnd", GroupEnd);
-    sym(h, "ncclAllGather", AllGather);
-    sym(h, "ncclGetErrorString", GetErrorString);
-    ok = CommInitAll && CommInitRank && GetUniqueId && CommDestroy && GroupStart && GroupEnd && AllGather;
-    return ok;
-  }
-  std::string text(ncclResult_t e) const { return GetErrorString ? std::string(GetErrorString(e)) : std::string("RCCL error ") + std::to_string((int)e); }
-};
-Rccl g_rccl;
-static_assert(std::is_same<decltype(Rccl::AllGather), ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t)>::value,
-              "ncclAllGather is called as (send, recv, bytes, ncclChar, comm, stream)");
-static_assert(sizeof(ncclUniqueId) == NBX_UNIQUE_ID_BYTES, "include/nbx.h promises callers the size of the rendezvous token");
-
-}  // namespace
-
-struct nbx_group {
-  int n = 0, precision = 32, P = 0, block = 0, n_alloc = 0;
-  int my_rank = -1;                  // >= 0: one-process-per-GPU group (nbx_group_create_rank): `rank` holds this process's context only
-  std::vector<nbx_ctx*> rank;
-  std::vector<int> dev;
-  std::vector<hipEvent_t> done;      // rank r's NEXT block is complete (copy path)
-  std::vector<Rccl::comm_t> comm;    // RCCL path
-  bool use_rccl = false;
-  double* ke_all = nullptr;          // rank groups: [P] sum m v^2 of every rank, all-gathered
-  void* vel_stage = nullptr;         // rank groups, nbx_group_download: own velocities padded to `block` records
-  void* vel_all = nullptr;           //   and the all-gathered [P * block] records
-};
-
-namespace {
-
-// Balanced, tile-aligned blocks; ranks that would own nothing are dropped (P is reduced).  The same arithmetic as
-// sharded.block_partition (tests/test_partition.py compares them) with that reduction applied.
-void partition(int n, int n_ranks, int* P_out, int* block_out) {
-  int P = n_ranks, block = 0;
-  for (;; --P) {
-    block = round_up(ceil_div(n, P), kTile);
-    if (P == 1 || (long long)(P - 1) * block < n) break;
-  }
-  *P_out = P;
-  *block_out = block;
-}
-
-int rccl_fail(const char* what, ncclResult_t e) { return fail(NBX_ERR_DEVICE, std::string(what) + ": " + g_rccl.text(e)); }
-
-int group_exchange(nbx_group* g) {
-  const size_t rec = g->rank[0]->rec;
-  if (g->use_rccl) {
-    // in place: rank r sends its own block, receives every block at its natural offset.  Once the group is open every
-    // path reaches ncclGroupEnd: an early return would leave RCCL in group mode for the rest of the process.
-    ncclResult_t e = g_rccl.GroupStart();
-    if (e != ncclSuccess) return rccl_fail("ncclGroupStart", e);
-    int rc = NBX_OK;
-    for (size_t k = 0; k < g->rank.size() && rc == NBX_OK; ++k) {
-      nbx_ctx* c = g->rank[k];
-      const int r = g->my_rank >= 0 ? g->my_rank : (int)k;
-      char* buf = (char*)c->posm[c->cur ^ 1];
-      const hipError_t he = hipSetDevice(g->dev[k]);
-      if (he != hipSuccess) { rc = fail(NBX_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(he)); break; }
-      e = g_rccl.AllGather(buf + (size_t)r * g->block * rec, buf, (size_t)g->block * rec, ncclChar, g->comm[k], c->stream);
-      if (e != ncclSuccess) rc = rccl_fail("ncclAllGather", e);
-    }
-    e = g_rccl.GroupEnd();
-    if (rc == NBX_OK && e != ncclSuccess) rc = rccl_fail("ncclGroupEnd", e);
-    return rc;
-  }
-  // copy path: every destination pulls every other rank's block, stream-ordered behind the producer's event
-  for (int r = 0; r < g->P; ++r) {
-    HIP_TRY(hipSetDevice(g->dev[r]));
-    HIP_TRY(hipEventRecord(g->done[r], g->rank[r]->stream));
-  }
-  for (int q = 0; q < g->P; ++q) {
-    nbx_ctx* dst = g->rank[q];
-    HIP_TRY(hipSetDevice(g->dev[q]));
-    for (int r = 0; r < g->P; ++r) {
-      if (r == q) continue;
-      nbx_ctx* src = g->rank[r];
-      const size_t off = (size_t)src->i_begin * rec, bytes = (size_t)src->i_count * rec;
-      HIP_TRY(hipStreamWaitEvent(dst->stream, g->done[r], 0));
-      char* d = (char*)dst->posm[dst->cur ^ 1] + off;
-      const char* s = (const char*)src->posm[src->cur ^ 1] + off;
-      if (g->dev[q] == g->dev[r]) HIP_TRY(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, dst->stream));
-      else HIP_TRY(hipMemcpyPeerAsync(d, g->dev[q], s, g->dev[r], bytes, dst->stream));
-    }
-  }
-  return NBX_OK;
-}
-
-int check_group_args(const char* who, nbx_group** out, int n, int precision, int n_ranks, const nbx_opts* opts, nbx_opts* o) {
-  if (!out) return fail(NBX_ERR_ARG, std::string(who) + ": out is NULL");
-  *out = nullptr;
-  if (n <= 0) return fail(NBX_ERR_ARG, std::string(who) + ": n must be > 0");
-  if (n_ranks <= 0 || n_ranks > 64) return fail(NBX_ERR_ARG, std::string(who) + ": the number of ranks must be in 1..64");
-  if (precision != 32 && precision != 64) return fail(NBX_ERR_ARG, std::string(who) + ": precision must be 32 or 64");
-  std::memset(o, 0, sizeof(*o));
-  if (opts) {
-    if (opts->struct_size != 0 && opts->struct_size != (int32_t)sizeof(nbx_opts))
-      return fail(NBX_ERR_ARG, std::string(who) + ": nbx_opts.struct_size does not match this library");
-    *o = *opts;
-  }
-  o->stream = nullptr; o->external_stream = 0; o->use_graph = 2;  // every rank: own stream, plain launches
-  return NBX_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-int nbx_partition(int32_t n, int32_t n_ranks, int32_t rank, int32_t* ranks_used, int32_t* block, int32_t* i_begin,
-                  int32_t* i_count, int32_t* n_alloc) {
-  return guarded("nbx_partition", [&]() -> int {
-  if (n <= 0 || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(NBX_ERR_ARG, "nbx_partition: need n > 0 and 0 <= rank < n_ranks");
-  int P = 0, b = 0;
-  partition(n, n_ranks, &P, &b);
-  const long long lo = std::min<long long>((long long)rank * b, n), hi = std::min<long long>((long long)(rank + 1) * b, n);
-  if (ranks_used) *ranks_used = P;
-  if (block) *block = b;
-  if (i_begin) *i_begin = (int32_t)lo;
-  if (i_count) *i_count = rank < P ? (int32_t)(hi - lo) : 0;  // ranks >= P own nothing and take no part
-  if (n_alloc) *n_alloc = P * b;
-  return NBX_OK;
-  });
-}
-
-int nbx_group_create(nbx_group** out, int32_t n, int32_t precision, int32_t n_ranks, const int32_t* devices,
-                     const nbx_opts* opts) {
-  return guarded("nbx_group_create", [&]() -> int {
-  nbx_opts o;
-  int rc = check_group_args("nbx_group_create", out, n, precision, n_ranks, opts, &o);
-  if (rc) return rc;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(NBX_ERR_DEVICE, "nbx_group_create: no HIP device available (libnbx has no CPU path)");
-  int P = 0, block = 0;
-  partition(n, n_ranks, &P, &block);
-  nbx_group* g = new (std::nothrow) nbx_group();
-  if (!g) return fail(NBX_ERR_ALLOC, "nbx_group_create: out of host memory");
-  struct Owner { nbx_group* g; ~Owner() { nbx_group_destroy(g); } } owner{g};  // every failure path below frees the group
-  g->n = n; g->precision = precision; g->P = P; g->block = block; g->n_alloc = P * block;
-  bool distinct = true;
-  for (int r = 0; r < P; ++r) {
-    const int d = devices ? devices[r] : r % ndev;
-    if (d < 0 || d >= ndev) return fail(NBX_ERR_ARG, "nbx_group_create: device ordinal out of range");
-    for (int q : g->dev) distinct = distinct && q != d;
-    g->dev.push_back(d);
-  }
-  for (int r = 0; r < P; ++r) {
-    o.device = g->dev[r];
-    o.i_begin = r * block;
-    o.i_count = std::min(n, (r + 1) * block) - r * block;
-    o.n_alloc = g->n_alloc;
-    nbx_ctx* c = nullptr;
-    rc = nbx_create(&c, n, precision, &o);
-    if (rc != NBX_OK) { const std::string m = g_err; return fail(rc, "nbx_group_create: rank " + std::to_string(r) + ": " + m); }
-    g->rank.push_back(c);
-  }
-  const char* force = std::getenv("NBX_EXCHANGE");  // "copy" forces the peer-copy path, "rccl" insists on RCCL
-  const bool insist = force && !std::strcmp(force, "rccl");  // also with a single rank: smoke-tests the RCCL binding
-  const bool want_rccl = distinct && (P > 1 || insist) && !(force && !std::strcmp(force, "copy"));
-  if (want_rccl && g_rccl.load()) {
-    g->comm.assign(P, nullptr);
-    const ncclResult_t e = g_rccl.CommInitAll(g->comm.data(), P, g->dev.data());
-    if (e == ncclSuccess) g->use_rccl = true;
-    else g->comm.clear();
-  }
-  if (insist && !g->use_rccl)
-    return fail(NBX_ERR_DEVICE, "nbx_group_create: NBX_EXCHANGE=rccl but RCCL is unavailable for these devices");
-  if (!g->use_rccl) {
-    g->done.assign(P, nullptr);
-    for (int r = 0; r < P; ++r) {
-      if (hipSetDevice(g->dev[r]) != hipSuccess || hipEventCreateWithFlags(&g->done[r], hipEventDisableTiming) != hipSuccess)
-        return fail(NBX_ERR_DEVICE, "nbx_group_create: hipEventCreate failed");
-      for (int q = 0; q < P; ++q)  // best effort: direct peer access speeds hipMemcpyPeerAsync up
-        if (g->dev[q] != g->dev[r]) { (void)hipDeviceEnablePeerAccess(g->dev[q], 0); (void)hipGetLastError(); }
-    }
-  }
-  owner.g = nullptr;
-  *out = g;
-  g_err.clear();
-  return NBX_OK;
-  });
-}
-
-int nbx_comm_unique_id(void* id_out) {
-  return guarded("nbx_comm_unique_id", [&]() -> int {
-  if (!id_out) return fail(NBX_ERR_ARG, "nbx_comm_unique_id: id_out is NULL");
-  if (!g_rccl.load()) return fail(NBX_ERR_DEVICE, "nbx_comm_unique_id: librccl could not be loaded");
-  ncclUniqueId id;
-  const ncclResult_t e = g_rccl.GetUniqueId(&id);
-  if (e != ncclSuccess) return rccl_fail("ncclGetUniqueId", e);
-  std::memcpy(id_out, &id, sizeof id);
-  return NBX_OK;
-  });
-}
-
-int nbx_group_create_rank(nbx_group** out, int32_t n, int32_t precision, int32_t world, int32_t rank, const void* unique_id,
-                          int32_t device, const nbx_opts* opts) {
-  return guarded("nbx_group_create_rank", [&]() -> int {
-  nbx_opts o;
-  int rc = check_group_args("nbx_group_create_rank", out, n, precision, world, opts, &o);
-  if (rc) return rc;
-  if (rank < 0 || rank >= world) return fail(NBX_ERR_ARG, "nbx_group_create_rank: rank must be in [0, world)");
-  if (!unique_id) return fail(NBX_ERR_ARG, "nbx_group_create_rank: unique_id is NULL");
-  int P = 0, block = 0;
-  partition(n, world, &P, &block);
-  // every rank computes the same P: a world too large for n is refused by ALL ranks alike (nobody is left waiting in a collective)
-  if (P != world)
-    return fail(NBX_ERR_ARG, "nbx_group_create_rank: " + std::to_string(n) + " bodies give only " + std::to_string(P) +
-                                 " non-empty blocks of 256-aligned size; start at most that many ranks");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(NBX_ERR_DEVICE, "nbx_group_create_rank: no HIP device available (libnbx has no CPU path)");
-  const int dev = device >= 0 ? device : rank % ndev;
-  if (dev >= ndev) return fail(NBX_ERR_ARG, "nbx_group_create_rank: device ordinal out of range");
-  if (!g_rccl.load()) return fail(NBX_ERR_DEVICE, "nbx_group_create_rank: librccl could not be loaded");
-  nbx_group* g = new (std::nothrow) nbx_group();
-  if (!g) return fail(NBX_ERR_ALLOC, "nbx_group_create_rank: out of host memory");
-  struct Owner { nbx_group* g; ~Owner() { nbx_group_destroy(g); } } owner{g};
-  g->n = n; g->precision = precision; g->P = P; g->block = block; g->n_alloc = P * block; g->my_rank = rank;
-  g->dev.push_back(dev);
-  o.device = dev;
-  o.i_begin = rank * block;
-  o.i_count = std::min(n, (rank + 1) * block) - rank * block;
-  o.n_alloc = g->n_alloc;
-  nbx_ctx* c = nullptr;
-  rc = nbx_create(&c, n, precision, &o);
-  if (rc != NBX_OK) { const std::string m = g_err; return fail(rc, "nbx_group_create_rank: rank " + std::to_string(rank) + ": " + m); }
-  g->rank.push_back(c);
-  HIP_TRY(hipSetDevice(dev));
-  HIP_TRY(hipMalloc(&g->ke_all, sizeof(double) * (size_t)P));
-  ncclUniqueId id;
-  std::memcpy(&id, unique_id, sizeof id);
-  g->comm.assign(1, nullptr);
-  const ncclResult_t e = g_rccl.CommInitRank(&g->comm[0], P, id, rank);
-  if (e != ncclSuccess) { g->comm.clear(); return rccl_fail("ncclCommInitRank", e); }
-  g->use_rccl = true;
-  owner.g = nullptr;
-  *out = g;
-  g_err.clear();
-  return NBX_OK;
-  });
-}
-
-void nbx_group_destroy(nbx_group* g) {
-  if (!g) return;
-  for (nbx_ctx* c : g->rank) if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
-  for (auto cm : g->comm) if (cm) (void)g_rccl.CommDestroy(cm);
-  for (size_t r = 0; r < g->done.size(); ++r) if (g->done[r]) { (void)hipSetDevice(g->dev[r]); (void)hipEventDestroy(g->done[r]); }
-  if (!g->dev.empty()) (void)hipSetDevice(g->dev[0]);
-  if (g->ke_all) (void)hipFree(g->ke_all);
-  if (g->vel_stage) (void)hipFree(g->vel_stage);
-  if (g->vel_all) (void)hipFree(g->vel_all);
-  for (nbx_ctx* c : g->rank) nbx_destroy(c);
-  delete g;
-}
-
-int nbx_group_upload(nbx_group* g, const void* px, const void* py, const void* pz, const void* vx, const void* vy,
-                     const void* vz, const void* m) {
-  return guarded("nbx_group_upload", [&]() -> int {
-  if (!g) return fail(NBX_ERR_ARG, "nbx_group_upload: group is NULL");
-  for (nbx_ctx* c : g->rank) {
-    const int rc = nbx_upload(c, px, py, pz, vx, vy, vz, m);
-    if (rc) return rc;
-  }
-  return NBX_OK;
-  });
-}
-
-int nbx_group_step(nbx_group* g, double dt, int32_t nsteps, double* kenergy_out) {
-  return guarded("nbx_group_step", [&]() -> int {
-  if (!g) return fail(NBX_ERR_ARG, "nbx_group_step: group is NULL");
-  if (nsteps < 0) return fail(NBX_ERR_ARG, "nbx_group_step: nsteps < 0");
-  for (int s = 0; s < nsteps; ++s) {
-    for (nbx_ctx* c : g->rank) {
-      const int rc = nbx_step_local(c, dt);
-      if (rc) return rc;
-    }
-    if (g->P > 1 || g->use_rccl) {
-      const int rc = group_exchange(g);
-      if (rc) return rc;
-    }
-    for (nbx_ctx* c : g->rank) {
-      const int rc = nbx_commit(c);
-      if (rc) return rc;
-    }
-  }
-  if (kenergy_out) {
-    double sum = 0.0;
-    if (g->my_rank >= 0) {
-      // one process per GPU: every rank reduces its partial on the device, one 8-byte all-gather, and all ranks add
-      // the P values in rank order -- the same number on every rank, independent of arrival order
-      nbx_ctx* c = g->rank[0];
-      int rc = use_device(c);
-      if (rc) return rc;
-      if (c->ke_parts > 0) {
-        rc = enqueue_ke_reduce(c, 0);
-        if (rc) return rc;
-      } else {
-        HIP_TRY(hipMemsetAsync(c->ke_dev, 0, sizeof(double), c->stream));
-      }
-      const ncclResult_t e = g_rccl.AllGather(c->ke_dev, g->ke_all, sizeof(double), ncclChar, g->comm[0], c->stream);
-      if (e != ncclSuccess) return rccl_fail("ncclAllGather(kenergy)", e);
-      std::vector<double> parts((size_t)g->P);
-      HIP_TRY(hipMemcpyAsync(parts.data(), g->ke_all, sizeof(double) * parts.size(), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(hipStreamSynchronize(c->stream));
-      for (double p : parts) sum += p;
-    } else {
-      for (nbx_ctx* c : g->rank) {  // rank order: deterministic
-        double part = 0.0;
-        const int rc = nbx_kenergy_partial(c, &part);
-        if (rc) return rc;
-        sum += part;
-      }
-      for (nbx_ctx* c : g->rank) {  // the exchange copies of the last step must have landed too
-        const int rc = nbx_sync(c);
-        if (rc) return rc;
-      }
-    }
-    *kenergy_out = 0.5 * sum;
-  }
-  return NBX_OK;
-  });
-}
-
-int nbx_group_download(nbx_group* g, void* px, void* py, void* pz, void* vx, void* vy, void* vz) {
-  return guarded("nbx_group_download", [&]() -> int {
-  if (!g) return fail(NBX_ERR_ARG, "nbx_group_download: group is NULL");
-  for (nbx_ctx* c : g->rank) {
-    const int rc = nbx_sync(c);
-    if (rc) return rc;
-  }
-  if (g->my_rank >= 0) {
-    // collective: every rank calls it.  Positions are complete on every rank; velocities live with their owners, so the
-    // owned blocks are all-gathered (padded to `block` records) -- afterwards every caller holds the full final state,
-    // as rank 0 of the reference does after mpi_gather (ver5_all/GSimulation.cpp:186-214).
-    nbx_ctx* c = g->rank[0];
-    int rc = nbx_download(c, px, py, pz, nullptr, nullptr, nullptr);
-    if (rc) return rc;
-    if (!vx && !vy && !vz) return NBX_OK;
-    rc = use_device(c);
-    if (rc) return rc;
-    const size_t rec = c->rec, blk = rec * (size_t)g->block;
-    if (!g->vel_stage) HIP_TRY(hipMalloc(&g->vel_stage, blk));
-    if (!g->vel_all) HIP_TRY(hipMalloc(&g->vel_all, blk * (size_t)g->P));
-    HIP_TRY(hipMemsetAsync(g->vel_stage, 0, blk, c->stream));
-    HIP_TRY(hipMemcpyAsync(g->vel_stage, c->velm, rec * (size_t)c->i_count, hipMemcpyDeviceToDevice, c->stream));
-    const ncclResult_t e = g_rccl.AllGather(g->vel_stage, g->vel_all, blk, ncclChar, g->comm[0], c->stream);
-    if (e != ncclSuccess) return rccl_fail("ncclAllGather(velocities)", e);
-    std::vector<char> h(rec * (size_t)g->n);
-    HIP_TRY(hipMemcpyAsync(h.data(), g->vel_all, h.size(), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < g->n; ++i) {
-      if (c->precision == 32) {
-        const float4& q = reinterpret_cast<const float4*>(h.data())[i];
-        if (vx) ((float*)vx)[i] = q.x;
-        if (vy) ((float*)vy)[i] = q.y;
-        if (vz) ((float*)vz)[i] = q.z;
-      } else {
-        const double4& q = reinterpret_cast<const double4*>(h.data())[i];
-        if (vx) ((double*)vx)[i] = q.x;
-        if (vy) ((double*)vy)[i] = q.y;
-        if (vz) ((double*)vz)[i] = q.z;
-      }
-    }
-    return NBX_OK;
-  }
-  for (size_t r = 0; r < g->rank.size(); ++r) {  // positions once (rank 0 holds all), velocities per owner
-    const int rc = nbx_download(g->rank[r], r == 0 ? px : nullptr, r == 0 ? py : nullptr, r == 0 ? pz : nullptr, vx, vy, vz);
-    if (rc) return rc;
-  }
-  return NBX_OK;
-  });
-}
-
-int nbx_group_info(nbx_group* g, int32_t* n_ranks, int32_t* uses_rccl, int32_t rank, nbx_stats_t* rank_stats) {
-  return guarded("nbx_group_info", [&]() -> int {
-  if (!g) return fail(NBX_ERR_ARG, "nbx_group_info: group is NULL");
-  if (n_ranks) *n_ranks = g->P;
-  if (uses_rccl) *uses_rccl = g->use_rccl ? 1 : 0;
-  if (rank_stats) {
-    if (rank < 0 || rank >= g->P) return fail(NBX_ERR_ARG, "nbx_group_info: rank out of range");
-    // a rank group holds this process's context only: its statistics are returned whatever rank is asked for
-    return nbx_stats(g->rank[g->my_rank >= 0 ? 0 : rank], rank_stats);
-  }
-  return NBX_OK;
-  });
-}
-
-}  // extern "C"
+static_assert(nbx::kTile == 256 && nbx::kBlock == 256, "nbx_group.hip aligns blocks to the kernels' 256-record j tile");
