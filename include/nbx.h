@@ -95,7 +95,7 @@ typedef struct nbx_opts {
                                   with the reference within the 1e-4 gate: 2e-5 over 500 steps at n = 131072) and for fp64
                                   (its summation noise is ~1e-13, far inside the 1e-10 gate either way) */
   int32_t inner_loop;      /* scheduling of the SGPR kernel's j loop: 0 = NBX_LOOP_AUTO (the hand-scheduled gfx950 loop wherever
-                              an instance exists: packed fp32, kernel_variant SGPR, 2 or 4 bodies per lane), 1 = NBX_LOOP_CXX
+                              an instance exists: packed fp32, kernel_variant SGPR or SGPRW, 2 or 4 bodies per lane, whole trips per wave), 1 = NBX_LOOP_CXX
                               (always the compiler-scheduled C++ loop), 2 = NBX_LOOP_ASM (fail if no instance fits the shape).
                               Both loops perform the same operations in the same order: results are bit-identical */
   int32_t reserved[2];

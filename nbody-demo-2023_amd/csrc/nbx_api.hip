@@ -55,7 +55,7 @@ void launch_force_t(const ForceArgs<T>& a, dim3 grid, hipStream_t st) {
 
 // does a hand-scheduled (LOOP_ASM) instance exist for this combination?
 template <typename T, int JSRC, int EPI, int MATH, bool WS>
-constexpr bool kHasAsmLoop = sizeof(T) == 4 && JSRC == JSRC_SGPR && MATH == MATH_PACKED && !WS;
+constexpr bool kHasAsmLoop = sizeof(T) == 4 && JSRC == JSRC_SGPR && MATH == MATH_PACKED;
 
 template <typename T>
 using ForceLauncher = void (*)(const ForceArgs<T>&, dim3, hipStream_t);
@@ -108,7 +108,8 @@ ForceLauncher<T> pick(int B, int variant, int epi, int loop) {
 // Does the hand-scheduled loop exist for this shape?  (mirror of kHasAsmLoop for run-time shape decisions)
 bool asm_loop_available(const nbx_ctx* c, int epi) {
   (void)epi;
-  return c->precision == 32 && c->variant == NBX_KERNEL_SGPR && c->math == MATH_PACKED && (c->B == 2 || c->B == 4);
+  if (c->variant == NBX_KERNEL_SGPRW && c->jps % 256 != 0) return false;  // a wave walks a quarter of a split: whole trips only
+  return c->precision == 32 && (c->variant == NBX_KERNEL_SGPR || c->variant == NBX_KERNEL_SGPRW) && c->math == MATH_PACKED && (c->B == 2 || c->B == 4);
 }
 
 template <typename T>
@@ -523,7 +524,7 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
     return fail(NBX_ERR_ARG, "nbx_create: inner_loop must be NBX_LOOP_AUTO, NBX_LOOP_CXX or NBX_LOOP_ASM");
   c->loop = (o.inner_loop != NBX_LOOP_CXX && asm_loop_available(c, c->epi)) ? LOOP_ASM : LOOP_CXX;
   if (o.inner_loop == NBX_LOOP_ASM && c->loop != LOOP_ASM)
-    return fail(NBX_ERR_ARG, "nbx_create: no hand-scheduled loop for this shape (needs fp32, kernel_variant SGPR, 2 or 4 bodies per lane)");
+    return fail(NBX_ERR_ARG, "nbx_create: no hand-scheduled loop for this shape (needs fp32, kernel_variant SGPR or SGPRW with j_per_split a multiple of 256, 2 or 4 bodies per lane)");
   // use_graph: 0 auto (launch-bound sizes only: < ~0.3 ms of pair work per step), 1 on, 2 off;
   // capture needs a stream of our own
   {

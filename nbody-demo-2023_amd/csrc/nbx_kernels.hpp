@@ -302,8 +302,8 @@ template <typename T, int B, int JSRC, int EPI, int MINW, int MATH = MATH_SCALAR
 __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> a) {
   using T4 = typename V4<T>::type;
   static_assert(!WSPLIT || (JSRC == JSRC_SGPR && EPI != EPI_ROW), "wave split exists for the SGPR kernel with slabs only");
-  static_assert(LOOP == LOOP_CXX || (JSRC == JSRC_SGPR && MATH == MATH_PACKED && !WSPLIT && sizeof(T) == 4 && (B == 2 || B == 4)),
-                "the hand-scheduled loop exists for the packed fp32 SGPR kernel with 2 or 4 bodies per lane");
+  static_assert(LOOP == LOOP_CXX || (JSRC == JSRC_SGPR && MATH == MATH_PACKED && sizeof(T) == 4 && (B == 2 || B == 4)),
+                "the hand-scheduled loop exists for the packed fp32 SGPR kernels with 2 or 4 bodies per lane");
   const int t = threadIdx.x;
   constexpr int kStride = WSPLIT ? 64 : kBlock;  // distance between a lane's consecutive bodies
   const int base = blockIdx.x * (kStride * B) + (WSPLIT ? (t & 63) : t);
@@ -349,7 +349,8 @@ __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> 
       cur ^= 1;
     }
   } else if constexpr (LOOP == LOOP_ASM) {
-    // j range = a positive multiple of kSgprAsmTrip<B> records (the host rounds j_per_split to 64; n_alloc is a multiple of 256)
+    // j range = a positive multiple of kSgprAsmTrip<B> records (the host rounds j_per_split to 64, to 256 under WSPLIT where a
+    // wave walks a quarter of it; n_alloc is a multiple of 256)
     if (j0 < j1) ib.apply_range_asm(a.posm + j0, a.posm + j1);
   } else {
     // Wave-uniform j index => the records travel by s_load_dwordx16 (64 B = kSgprBatch records) into

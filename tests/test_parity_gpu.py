@@ -1128,10 +1128,37 @@ def test_hand_scheduled_loop_is_bit_equal_to_the_compiled_loop(nbx, n, own, step
         assert res[0][2] == res[1][2], shape
 
 
+@pytest.mark.parametrize("n,S,steps", [(16384, 32, 10), (16384, 8, 6), (65536, 32, 3), (4096, 16, 20)])
+@pytest.mark.parametrize("B", [2, 4])
+def test_hand_scheduled_loop_in_the_wave_split_kernel_is_bit_equal_too(nbx, n, S, steps, B):
+    """SGPRW (tree order: the four waves of a workgroup split each j range) takes the same generated loop whenever a wave's
+    quarter of a split is a whole number of trips (j_per_split a multiple of 256): same bits as the compiled loop."""
+    ic = nbx.initial_conditions(n)
+    res = []
+    for loop in (nbx.LOOP_ASM, nbx.LOOP_CXX):
+        with nbx.Context(n, 32, kernel_variant=nbx.KERNEL_SGPRW, bodies_per_lane=B, j_split=S, inner_loop=loop, use_graph=2) as c:
+            c.upload(ic)
+            acc = c.accel()
+            ke = c.step_trace(steps)
+            st = c.stats()
+            assert st["inner_loop"] == loop and st["kernel_variant"] == nbx.KERNEL_SGPRW and st["j_split"] == S
+            res.append((acc, ke, c.download()))
+    for k in range(3):
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
+    assert np.array_equal(res[0][1], res[1][1])
+    for f in res[0][2]:
+        assert np.array_equal(res[0][2][f], res[1][2][f]), f
+    with pytest.raises(nbx.NbxError):  # j_per_split = 96: a wave's quarter is not a whole trip
+        nbx.Context(n, 32, kernel_variant=nbx.KERNEL_SGPRW, bodies_per_lane=B, j_split=n // 96, inner_loop=nbx.LOOP_ASM)
+
+
 def test_hand_scheduled_loop_is_the_default_where_it_exists(nbx):
     with nbx.Context(262144, 32) as c:  # configs[2]: reference order, SGPR kernel, packed math
         st = c.stats()
         assert st["summation_order"] == nbx.ORDER_REFERENCE and st["inner_loop"] == nbx.LOOP_ASM
+    with nbx.Context(65536, 32) as c:  # tree order, wave-split kernel: 2048 records per split
+        st = c.stats()
+        assert st["kernel_variant"] == nbx.KERNEL_SGPRW and st["inner_loop"] == nbx.LOOP_ASM
     with nbx.Context(4099, 32, kernel_variant=nbx.KERNEL_LDS) as c:
         assert c.stats()["inner_loop"] == nbx.LOOP_CXX
     with pytest.raises(nbx.NbxError):
