@@ -113,7 +113,7 @@ typedef struct nbx_stats_t {
   double  force_ms_total;      /* sum of HIP-event durations of those launches (profiling on) */
   double  pairs_per_launch;    /* i_count * n */
   char    device_name[64];
-  int64_t graph_replays;       /* hipGraph launches issued by nbx_step (each covers up to 20 steps) */
+  int64_t graph_replays;       /* hipGraph launches issued by nbx_step (each covers up to 50 steps) */
   int32_t use_graph;           /* 1 if nbx_step replays windows from a hipGraph */
   int32_t inner_loop;          /* NBX_LOOP_CXX or NBX_LOOP_ASM actually in use by the step kernel */
 } nbx_stats_t;

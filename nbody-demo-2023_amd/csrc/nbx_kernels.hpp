@@ -499,6 +499,16 @@ __global__ __launch_bounds__(kBlock, 1) void force_jlane_kernel(const ForceArgs<
     ax[b / 2][b & 1] = 0.f; ay[b / 2][b & 1] = 0.f; az[b / 2][b & 1] = 0.f;
   }
 
+  // the body lane t < NB will integrate at the end: its position and velocity are requested now, so that the two loads
+  // land under the j loop instead of in front of the epilogue (at n = 2048 the whole launch is a few microseconds)
+  const int li = b0 + lane;
+  const bool mine = lane < NB && li < a.i_count;
+  float4 pe = make_float4(0.f, 0.f, 0.f, 0.f), ve = pe;
+  if (mine) {
+    pe = a.posm[a.i_begin + li];
+    ve = a.velm[li];
+  }
+
   // Two register sets of D records ping-pong: the loads of the NEXT D records are issued before the current D are
   // applied, so a request has D x NB/2 x 56 cycles of arithmetic to land under (one wave per SIMD has no other wave to
   // hide an L2 round trip behind).  Requests may run up to D blocks past the end of the array (zero-filled spare records,
@@ -559,8 +569,7 @@ __global__ __launch_bounds__(kBlock, 1) void force_jlane_kernel(const ForceArgs<
   for (int b = 0; b < NB; ++b) red[w][b][lane] = make_float4(ax[b / 2][b & 1], ay[b / 2][b & 1], az[b / 2][b & 1], 0.f);
   __builtin_amdgcn_wave_barrier();  // same wave, in-order LDS queue: the reads below see the writes above
   double ke = 0.0;
-  const int li = b0 + lane;
-  if (lane < NB && li < a.i_count) {
+  if (mine) {
     float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll 8
     for (int l = 0; l < 64; ++l) {
@@ -570,11 +579,9 @@ __global__ __launch_bounds__(kBlock, 1) void force_jlane_kernel(const ForceArgs<
     if (acc_only) {
       a.accp[li] = make_float4(sx, sy, sz, 0.f);
     } else {
-      float4 p = a.posm[a.i_begin + li];
-      float4 v = a.velm[li];
-      ke = (double)euler_update<float>(sx, sy, sz, a.dt, p, v);
-      a.velm[li] = v;
-      a.posm_next[a.i_begin + li] = p;
+      ke = (double)euler_update<float>(sx, sy, sz, a.dt, pe, ve);
+      a.velm[li] = ve;
+      a.posm_next[a.i_begin + li] = pe;
     }
   }
   // one energy partial per workgroup, fixed order (wave shuffle tree, then the four waves)

@@ -263,7 +263,7 @@ def test_step_k_equals_k_single_steps_and_is_deterministic(nbx):
             assert np.array_equal(da[f], db[f]), f
 
 
-@pytest.mark.parametrize("n,steps", [(2000, 50), (2000, 7), (777, 45), (4099, 23), (16384, 4)])
+@pytest.mark.parametrize("n,steps", [(2000, 50), (2000, 7), (777, 45), (4099, 23), (16384, 4), (2000, 120), (16384, 101)])
 def test_graph_replay_is_bit_equal_to_plain_launches(nbx, n, steps):
     """nbx_step replays launch-bound windows from a hipGraph; it must be the same launches, same bits."""
     ic = nbx.initial_conditions(n)
