@@ -943,14 +943,16 @@ def test_config2_all_200_steps_against_the_real_reference(nbx):
 
 
 
-_CONFIG3_FIXTURE = os.path.join(ROOT, "tests", "golden", "ver7_f32_n1048576_s3.json")
+_CONFIG3_FIXTURES = [f for f in ("ver7_f32_n1048576_s3.json", "ver7_f32_n1048576_s10.json") if os.path.exists(os.path.join(ROOT, "tests", "golden", f))]
 
 
-@pytest.mark.skipif(not os.path.exists(_CONFIG3_FIXTURE), reason="fixture of configs[3]'s first steps (40 min of the reference's CPU binary) not generated")
-def test_config3_first_steps_against_the_real_reference(nbx):
-    """BASELINE.json configs[3]'s size (n = 1048576) against the reference's own binary for its first 3 steps (12 min of CPU
-    per step here): one context, 8 logical ranks of 131072 bodies (the 8-GPU partition) and the exact mode."""
-    g = load_golden("ver7_f32_n1048576_s3.json")
+@pytest.mark.skipif(not _CONFIG3_FIXTURES, reason="fixtures of configs[3]'s first steps (12-15 min of the reference's CPU binary per step) not generated")
+@pytest.mark.parametrize("name", _CONFIG3_FIXTURES or ["none"])
+def test_config3_first_steps_against_the_real_reference(nbx, name):
+    """BASELINE.json configs[3]'s size (n = 1048576) against the reference's own binary for its first 3 (and, second fixture,
+    10) steps -- 12-15 min of CPU per step here: one context, 8 logical ranks of 131072 bodies (the 8-GPU partition) and
+    the exact mode."""
+    g = load_golden(name)
     n, k = g["n"], g["nsteps"]
     ref = np.array(g["kenergy"])
     ic = nbx.initial_conditions(n)
@@ -965,8 +967,8 @@ def test_config3_first_steps_against_the_real_reference(nbx):
         c.upload(ic)
         ke = c.step_trace(k)
         d = c.download()
-    _dump("parity_config3_vs_real_reference.json", {"one_context": [float(x) for x in e1], "eight_logical_ranks_last_step": float(e8),
-                                                    "exact_mode_kenergy": [float(x) for x in rel_err(ke, ref)]})
+    _dump("parity_config3_vs_real_reference_s%d.json" % k, {"one_context": [float(x) for x in e1], "eight_logical_ranks_last_step": float(e8),
+                                                            "exact_mode_kenergy": [float(x) for x in rel_err(ke, ref)]})
     assert e1.max() < 1e-5 and e8 < 1e-5, (e1, e8)
     for f in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z"):
         assert _crc(d[f]) == g["final"][f]["crc32"], f
