@@ -128,7 +128,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=0, help="override the body count")
+    ap.add_argument("--n", "--bodies", dest="n", type=int, default=0,
+                    help="override the body count (under torch.distributed.run spell it --bodies: its parser takes --n for an abbreviation of its own options)")
     ap.add_argument("--precision", type=int, default=32, choices=(32, 64))
     ap.add_argument("--cpu-baseline", default="auto", choices=("auto", "reference", "port", "none"))
     ap.add_argument("--bodies-per-lane", type=int, default=0)
@@ -137,6 +138,12 @@ def main():
     ap.add_argument("--order", default="auto", choices=("auto", "reference", "tree"),
                     help="summation order of a body's pair terms (include/nbx.h): reference = the CPU loop's order")
     a = ap.parse_args()
+
+    # stdout carries ONE JSON line and nothing else: native libraries write there too (RCCL prints a version banner on
+    # rank 0 at communicator creation), so file descriptor 1 points at stderr until the line is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -333,7 +340,10 @@ def main():
             line["gpu_over_cpu"] = value / cpu["value"]
         if cpu_o3:
             line["cpu_baseline_o3"] = cpu_o3
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
 
     sim.close()
     if use_dist:
