@@ -100,3 +100,21 @@ def test_init_mpi_shares_follow_the_native_partition(nbx, tmp_path):
             out = subprocess.check_output([exe], env=dict(os.environ, NBODY_WORLD=str(world), NBODY_RANK=str(rank)), text=True).split()
             shares = [nbx.partition(4099, world, r)[3] for r in range(world)]
             assert [int(x) for x in out] == [rank, world, shares[rank]] + shares
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="checks the no-GPU failure mode of the one-process-per-GPU drop-in")
+def test_two_process_nbody_x_without_a_gpu_ends_on_both_ranks_at_once():
+    """Rank 0 cannot make an RCCL token without a HIP device: it says so, answers rank 1's hello with a refusal, and both
+    processes exit 1 within seconds -- nobody waits out the rendezvous timeout, nothing falls back to a CPU path."""
+    exe = os.path.join(HOST, "nbody.x")
+    port = str(_free_port())
+    env = dict(os.environ, NBODY_WORLD="2", NBODY_MASTER_PORT=port, NBODY_RENDEZVOUS_TIMEOUT="60")
+    t0 = time.time()
+    p1 = subprocess.Popen([exe, "3000", "10"], env=dict(env, NBODY_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    p0 = subprocess.Popen([exe, "3000", "10"], env=dict(env, NBODY_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    o0, e0 = p0.communicate(timeout=90)
+    o1, e1 = p1.communicate(timeout=90)
+    assert time.time() - t0 < 45
+    assert p0.returncode == 1 and "nbx_comm_unique_id failed" in e0 and "told to stop" in e0
+    assert p1.returncode == 1 and "rank 0 could not initialise" in e1
+    assert "Initialize Gravity Simulation" in o0 and o1 == ""  # only rank 0 prints
