@@ -1154,6 +1154,42 @@ def test_hand_scheduled_loop_in_the_wave_split_kernel_is_bit_equal_too(nbx, n, S
         nbx.Context(n, 32, kernel_variant=nbx.KERNEL_SGPRW, bodies_per_lane=B, j_split=n // 96, inner_loop=nbx.LOOP_ASM)
 
 
+def test_hand_scheduled_loop_bit_equal_on_adversarial_states(nbx):
+    """Not only the seed-42 cloud: clustered bodies (many pairs at r^2 = softening), coincident bodies, masses spanning twelve
+    decades, zero masses, a far-away outlier -- whatever the operands, the two loops must produce the same bits."""
+    rng = np.random.default_rng(7)
+    n = 8192
+    st8 = {f: np.zeros(n, dtype=np.float32) for f in nbx.FIELDS}
+    centres = rng.random((16, 3), dtype=np.float32)
+    k = rng.integers(0, 16, n)
+    spread = np.float32(10.0) ** rng.uniform(-7, -1, n).astype(np.float32)
+    for a, f in enumerate(("pos_x", "pos_y", "pos_z")):
+        st8[f] = (centres[k, a] + spread * rng.standard_normal(n).astype(np.float32)).astype(np.float32)
+    st8["pos_x"][1::97] = st8["pos_x"][0]; st8["pos_y"][1::97] = st8["pos_y"][0]; st8["pos_z"][1::97] = st8["pos_z"][0]  # coincident
+    st8["pos_x"][5] = np.float32(3.0e3)                                                                                     # outlier
+    for f in ("vel_x", "vel_y", "vel_z"):
+        st8[f] = (1e-3 * rng.standard_normal(n)).astype(np.float32)
+    st8["mass"] = (np.float32(10.0) ** rng.uniform(-6, 6, n).astype(np.float32)).astype(np.float32)
+    st8["mass"][::13] = 0.0
+    for variant, shapes in ((nbx.KERNEL_SGPR, (dict(j_split=1), dict(j_split=4))), (nbx.KERNEL_SGPRW, (dict(j_split=8),))):
+        for B in (2, 4):
+            for shape in shapes:
+                res = []
+                for loop in (nbx.LOOP_ASM, nbx.LOOP_CXX):
+                    with nbx.Context(n, 32, kernel_variant=variant, bodies_per_lane=B, inner_loop=loop, use_graph=2, **shape) as c:
+                        c.upload(st8)
+                        acc = c.accel()
+                        ke = c.step_trace(6)
+                        assert c.stats()["inner_loop"] == loop
+                        res.append((acc, ke, c.download()))
+                assert all(np.isfinite(x).all() for x in res[0][0])
+                for q in range(3):
+                    assert np.array_equal(res[0][0][q], res[1][0][q]), (variant, B, shape, q)
+                assert np.array_equal(res[0][1], res[1][1]), (variant, B, shape)
+                for f in res[0][2]:
+                    assert np.array_equal(res[0][2][f], res[1][2][f]), (variant, B, shape, f)
+
+
 def test_hand_scheduled_loop_is_the_default_where_it_exists(nbx):
     with nbx.Context(262144, 32) as c:  # configs[2]: reference order, SGPR kernel, packed math
         st = c.stats()
