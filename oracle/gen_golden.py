@@ -44,7 +44,9 @@ CASES = [
 #   OMP_NUM_THREADS=7 python oracle/gen_golden.py --only f32:262144:200   (2.7 h: the whole of configs[2])
 #   python oracle/gen_golden.py --only f32:1048576:3     (40 min: the first steps at configs[3]'s size)
 #   python oracle/gen_golden.py --only f64:262144:50     (over an hour: configs[4] up to its first printed row)
-BIG_CASES = [("f32", 262144, 7), ("f64", 262144, 3), ("f32", 32768, 500), ("f32", 65536, 500), ("f32", 262144, 200), ("f32", 1048576, 3), ("f64", 262144, 50)]
+#   OMP_NUM_THREADS=6 python oracle/gen_golden.py --only f32:1048576:10    (2.5 h: ten steps at configs[3]'s size, round 2)
+BIG_CASES = [("f32", 262144, 7), ("f64", 262144, 3), ("f32", 32768, 500), ("f32", 65536, 500), ("f32", 262144, 200), ("f32", 1048576, 3), ("f64", 262144, 50),
+             ("f32", 1048576, 10)]
 
 
 def run_case(prec, n, steps, nsample=8):
