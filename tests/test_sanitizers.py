@@ -14,3 +14,29 @@ def test_host_code_under_asan_ubsan(tmp_path):
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
     assert p.returncode == 0, p.stdout + p.stderr
     assert "sanitized host code: ok" in p.stdout
+
+
+def test_rendezvous_under_asan_ubsan(tmp_path):
+    """host/rendezvous.hpp (sockets, fixed-size structs copied in and out) with three ranks, every process sanitized."""
+    import socket
+    exe = str(tmp_path / "rdv_san")
+    subprocess.check_call(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I", os.path.join(ROOT, "nbody-demo-2023_amd", "host"), os.path.join(ROOT, "tests", "rendezvous_driver.cpp"),
+                           "-o", exe, "-lpthread"])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0")
+    procs = [subprocess.Popen([exe, str(r), "3", port, "1000"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in (1, 0, 2)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0 and o.startswith("ok 030a11"), (o, e)
+    # and the refusal path (a rank from another job)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    procs = [subprocess.Popen([exe, str(r), "2", port, n, "5"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r, n in ((0, "1000"), (1, "2000"))]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 1 for p in procs) and all("runtime error" not in e and "AddressSanitizer" not in e for _, e in outs), outs
