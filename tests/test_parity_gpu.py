@@ -1190,6 +1190,44 @@ def test_hand_scheduled_loop_bit_equal_on_adversarial_states(nbx):
                     assert np.array_equal(res[0][2][f], res[1][2][f]), (variant, B, shape, f)
 
 
+def test_hand_scheduled_loop_bit_equal_over_random_sizes_slices_and_splits(nbx):
+    """80 seeded random combinations of n (ragged), owned slice, bodies per lane, kernel, j-split: wherever an asm instance
+    exists for the shape it must agree with the compiled loop bit for bit (accelerations and two steps)."""
+    rng = np.random.default_rng(2024)
+    checked = 0
+    for _ in range(80):
+        n = int(rng.integers(300, 40000))
+        blk = -(-n // 256) * 256
+        i_begin = int(rng.integers(0, max(1, n // 2)))
+        i_count = int(rng.integers(1, n - i_begin + 1))
+        B = int(rng.choice([2, 4]))
+        variant = int(rng.choice([nbx.KERNEL_SGPR, nbx.KERNEL_SGPRW]))
+        S = int(rng.choice([1, 2, 3, 5, 8, 16])) if variant == nbx.KERNEL_SGPR else int(rng.choice([1, 2, 4, 8]))
+        opts = dict(kernel_variant=variant, bodies_per_lane=B, j_split=S, i_begin=i_begin, i_count=i_count, n_alloc=blk, use_graph=2)
+        try:
+            ca = nbx.Context(n, 32, inner_loop=nbx.LOOP_ASM, **opts)
+        except nbx.NbxError:
+            continue  # no instance for this shape (a wave's quarter of a split is not a whole trip)
+        ic = nbx.initial_conditions(n)
+        with ca, nbx.Context(n, 32, inner_loop=nbx.LOOP_CXX, **opts) as cc:
+            out = []
+            for c in (ca, cc):
+                c.upload(ic)
+                acc = c.accel()
+                for _k in range(2):
+                    c.step_local()
+                    c.commit()
+                out.append((acc, c.download(), c.kenergy_partial()))
+            assert ca.stats()["inner_loop"] == nbx.LOOP_ASM and cc.stats()["inner_loop"] == nbx.LOOP_CXX
+        for q in range(3):
+            assert np.array_equal(out[0][0][q], out[1][0][q]), (n, opts, q)
+        for f in out[0][1]:
+            assert np.array_equal(out[0][1][f], out[1][1][f]), (n, opts, f)
+        assert out[0][2] == out[1][2], (n, opts)
+        checked += 1
+    assert checked >= 40, checked
+
+
 def test_hand_scheduled_loop_is_the_default_where_it_exists(nbx):
     with nbx.Context(262144, 32) as c:  # configs[2]: reference order, SGPR kernel, packed math
         st = c.stats()
