@@ -85,7 +85,8 @@ struct nbx_group {
 namespace {
 
 // Balanced, tile-aligned blocks; ranks that would own nothing are dropped (P is reduced).  The same arithmetic as
-// sharded.block_partition (tests/test_partition.py compares them) with that reduction applied.
+// sharded.block_partition (tests/test_sharded_gloo.py::test_check_world_matches_the_native_partition compares them) with that
+// reduction applied.
 void partition(int n, int n_ranks, int* P_out, int* block_out) {
   int P = n_ranks, block = 0;
   for (;; --P) {
