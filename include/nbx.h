@@ -50,8 +50,8 @@ enum {
                            one thread per body, j strictly ascending, unfused IEEE multiply/add in the source's
                            association, correctly rounded sqrt and divide, G and m multiplied separately.  Positions
                            and velocities then equal the CPU ver7 run exactly (tests compare CRC-32 of whole arrays) */
-  NBX_KERNEL_JLANE = 6, /* fp32, tree order, launch-bound sizes (auto up to 32768 owned bodies): a wave owns `bodies_per_lane`
-                           (2, 4, 8 or 16) bodies wave-uniformly and its 64 lanes split the j records; lane partials meet in LDS
+  NBX_KERNEL_JLANE = 6, /* tree order, launch-bound sizes (auto up to 12288 owned bodies): a wave owns `bodies_per_lane`
+                           (2, 4, 8 or, fp32 only, 16) bodies wave-uniformly and its 64 lanes split the j records; lane partials meet in LDS
                            and the wave integrates its bodies itself -- ONE launch per time step, no slabs, no integrate kernel */
   NBX_KERNEL_EXACT_FMA = 5 /* diagnostic: NBX_KERNEL_EXACT with FMA contraction allowed -- what a -march=native / icpc -xAVX2
                            build of the same reference loop computes.  Used to show how far two builds of the REFERENCE

@@ -40,6 +40,7 @@ constexpr int kTreeOrderMaxN = 131072;
 // (12288: 41 us against SGPRW's 48; at 16384 the two tie at 67 us, and SGPRW's summation tree happens to be the one whose
 // chaotic n = 16384 x 500 run stays inside the 1e-4 gate at every printed step: profiles/r02_config1_by_kernel.txt)
 constexpr int kJlaneMaxOwn = 12288;
+constexpr int kJlaneMaxOwnF64 = 12288;  // fp64 form: 92 us against 97 at 12288, SGPRW ahead at 16384 (profiles/r02_jlane_f64_ab.txt)
 
 }  // namespace
 
@@ -193,21 +194,22 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   }
   // Launch-bound sizes (fp32): one launch per step with the lanes of a wave splitting j (force_jlane_kernel).  Bodies per
   // wave: the power of two that gives about one wave per SIMD (1024 waves), between 2 and 16.
-  const bool jlane_auto = variant == NBX_KERNEL_AUTO && c->precision == 32 && o.j_split <= 0 && o.bodies_per_lane == 0 &&
-                          o.fused_epilogue != 2 && c->i_count <= kJlaneMaxOwn;
-  if ((variant == NBX_KERNEL_JLANE && c->precision == 32) || jlane_auto) {
+  const int max_nb = c->precision == 32 ? 16 : 8;  // fp64 bodies take two SGPRs per coordinate
+  const bool jlane_auto = variant == NBX_KERNEL_AUTO && o.j_split <= 0 && o.bodies_per_lane == 0 && o.fused_epilogue != 2 &&
+                          c->i_count <= (c->precision == 32 ? kJlaneMaxOwn : kJlaneMaxOwnF64);
+  if (variant == NBX_KERNEL_JLANE || jlane_auto) {
     int NB = o.bodies_per_lane;
-    if (NB != 2 && NB != 4 && NB != 8 && NB != 16) {
+    if ((NB != 2 && NB != 4 && NB != 8 && NB != 16) || NB > max_nb) {
       // A launch lasts as long as the fullest SIMD: ceil(waves / SIMDs) rounds of NB bodies each.  Fewest body-rounds wins;
       // ties go to the larger NB (fewer waves stream the j records, fewer LDS transposes) -- the measured optimum at every
       // size from 2048 to 32768 (profiles/r02_jlane_ab.txt: 2048 -> 2, 4096 -> 4, 8192 -> 8, 12288 -> 4, 16384 -> 16).
       long best = 0;
-      for (int nb = 2; nb <= 16; nb *= 2) {
+      for (int nb = 2; nb <= max_nb; nb *= 2) {
         const long cost = (long)ceil_div(ceil_div(c->i_count, nb), cus * 4) * nb;
         if (best == 0 || cost <= best) { best = cost; NB = nb; }
       }
     }
-    c->B = NB; c->S = 1; c->jps = c->n_alloc; c->math = MATH_PACKED; c->variant = NBX_KERNEL_JLANE; c->epi = EPI_ROW;
+    c->B = NB; c->S = 1; c->jps = c->n_alloc; c->math = c->precision == 32 ? MATH_PACKED : MATH_SCALAR; c->variant = NBX_KERNEL_JLANE; c->epi = EPI_ROW;
     c->grid = dim3(ceil_div(ceil_div(c->i_count, NB), 4), 1);
     return;
   }
@@ -286,7 +288,12 @@ int enqueue_force(nbx_ctx* c, int epi, double dt) {
         default: hipLaunchKernelGGL((force_jlane_kernel<16, 4>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only); break;
       }
     } else {
-      return fail(NBX_ERR_ARG, "NBX_KERNEL_JLANE exists in fp32 only");
+      const int acc_only = epi == EPI_SLAB ? 1 : 0;
+      switch (c->B) {
+        case 2: hipLaunchKernelGGL((force_jlane_kernel_f64<2, 8>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only); break;
+        case 4: hipLaunchKernelGGL((force_jlane_kernel_f64<4, 4>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only); break;
+        default: hipLaunchKernelGGL((force_jlane_kernel_f64<8, 4>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only); break;
+      }
     }
   } else {
     fn(a, c->grid, c->stream);

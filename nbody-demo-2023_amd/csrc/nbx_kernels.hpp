@@ -589,6 +589,86 @@ __global__ __launch_bounds__(kBlock, 1) void force_jlane_kernel(const ForceArgs<
   if (threadIdx.x == 0 && !acc_only) a.ke_part[blockIdx.x] = s;
 }
 
+// The fp64 form of force_jlane_kernel: same decomposition (a wave owns NB bodies wave-uniformly, its lanes split j, LDS
+// transpose, the wave integrates its own bodies), plain fp64 arithmetic (pair<double>: there is no packed fp64), records
+// of 32 bytes.  NB <= 8: eight bodies are 48 SGPRs of coordinates.
+template <int NB, int D>
+__global__ __launch_bounds__(kBlock, 1) void force_jlane_kernel_f64(const ForceArgs<double> a, const int acc_only) {
+  static_assert(NB >= 1 && NB <= 8 && D >= 1 && D <= 8, "body state must fit the SGPR file; prefetch within the spare records");
+  __shared__ double4 red[4][NB][65];  // [wave][body][lane] + one column of padding (2080 B between the lanes that read)
+  __shared__ double ksum[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + w);
+  const int b0 = wave * NB;
+  double xi[NB], yi[NB], zi[NB], ax[NB], ay[NB], az[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    int li = b0 + b;
+    li = li < a.i_count ? li : a.i_count - 1;
+    const double4 p = a.posm[a.i_begin + li];  // wave-uniform index: scalar loads
+    xi[b] = p.x; yi[b] = p.y; zi[b] = p.z;
+    ax[b] = ay[b] = az[b] = 0.0;
+  }
+  const int li = b0 + lane;
+  const bool mine = lane < NB && li < a.i_count;
+  double4 pe = make_double4(0.0, 0.0, 0.0, 0.0), ve = pe;
+  if (mine) {
+    pe = a.posm[a.i_begin + li];
+    ve = a.velm[li];
+  }
+  const double4* pj = a.posm + lane;
+  const int K = a.n_alloc >> 6;
+  double4 ra[D], rb[D];
+  auto request = [&](double4 (&r)[D], int k0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) r[d] = pj[(size_t)64 * (k0 + d)];
+  };
+  auto apply_record = [&](const double4& r) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) pair<double>(r.x, r.y, r.z, r.w, xi[b], yi[b], zi[b], ax[b], ay[b], az[b]);
+  };
+  int k = 0;
+  request(ra, 0);
+  for (; k + 2 * D <= K; k += 2 * D) {
+    request(rb, k + D);
+#pragma unroll
+    for (int d = 0; d < D; ++d) apply_record(ra[d]);
+    request(ra, k + 2 * D);
+#pragma unroll
+    for (int d = 0; d < D; ++d) apply_record(rb[d]);
+  }
+  if (k < K) {
+    request(rb, k + D);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (k + d < K) apply_record(ra[d]);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (k + D + d < K) apply_record(rb[d]);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) red[w][b][lane] = make_double4(ax[b], ay[b], az[b], 0.0);
+  __builtin_amdgcn_wave_barrier();
+  double ke = 0.0;
+  if (mine) {
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+#pragma unroll 8
+    for (int l = 0; l < 64; ++l) {
+      const double4 q = red[w][lane][l];
+      sx += q.x; sy += q.y; sz += q.z;
+    }
+    if (acc_only) {
+      a.accp[li] = make_double4(sx, sy, sz, 0.0);
+    } else {
+      ke = euler_update<double>(sx, sy, sz, a.dt, pe, ve);
+      a.velm[li] = ve;
+      a.posm_next[a.i_begin + li] = pe;
+    }
+  }
+  const double s = block_sum(ke, ksum);
+  if (threadIdx.x == 0 && !acc_only) a.ke_part[blockIdx.x] = s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // force_exact_kernel (NBX_KERNEL_EXACT): the reference's acceleration loop with the reference's rounding.
 // The pinned build of ver7 (g++ -O2, x86-64 baseline) compiles ver7/GSimulation.cpp:153-173 to a scalar,

@@ -97,6 +97,33 @@ def test_jlane_accelerations_vs_oracle(nbx, oracle, n, NB):
     assert _acc_err((ax, ay, az), ref) < 1e-5
 
 
+@pytest.mark.parametrize("NB", [2, 4, 8])
+@pytest.mark.parametrize("n", [1, 5, 65, 257, 2000, 4099])
+def test_jlane_fp64_accelerations_vs_oracle(nbx, oracle, n, NB):
+    ref = _oracle_acc(oracle, n, np.float64)
+    ax, ay, az, st = _gpu_acc(nbx, n, 64, kernel_variant=nbx.KERNEL_JLANE, bodies_per_lane=NB)
+    assert st["kernel_variant"] == nbx.KERNEL_JLANE and st["bodies_per_lane"] == NB and st["precision"] == 64
+    assert _acc_err((ax, ay, az), ref) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["ver7_f64_n5_s20.json", "ver7_f64_n2000_s500.json", "ver7_f64_n4099_s40.json"])
+def test_jlane_fp64_traces_against_the_reference_fp64_build(nbx, name):
+    """The fp64 variant's gate (1e-10) with the one-launch kernel, which is the default at these sizes; graph replay on."""
+    g = load_golden(name)
+    n, steps = g["n"], g["nsteps"]
+    with nbx.Context(n, 64) as c:
+        c.upload(nbx.initial_conditions(n, 64))
+        ke = c.step_trace(steps)
+        assert c.stats()["kernel_variant"] == nbx.KERNEL_JLANE
+    assert rel_err(ke, g["kenergy"]).max() < 1e-10
+    with nbx.Context(n, 64, use_graph=1) as c, nbx.Context(n, 64, kernel_variant=nbx.KERNEL_SGPRW) as t:
+        ic = nbx.initial_conditions(n, 64)
+        c.upload(ic)
+        t.upload(ic)
+        assert c.step(steps) == ke[-1]                       # replayed from a graph: same bits
+        assert abs(t.step(steps) / ke[-1] - 1.0) < 1e-12     # the two-launch tree shape: another tree, same answer
+
+
 @pytest.mark.parametrize("n,steps,NB", [(2000, 500, 0), (4099, 40, 0), (1000, 100, 16), (65, 20, 4), (5, 20, 2), (8192, 30, 0)])
 def test_jlane_trajectory_matches_the_two_launch_tree_shape_and_the_reference(nbx, n, steps, NB):
     """force + Euler + energy in one launch: kinetic energy within rounding of the SGPRW + integrate_kernel pair at every step,
@@ -154,8 +181,9 @@ def test_jlane_is_the_default_for_launch_bound_sizes_and_shards_like_the_others(
     for n, want in ((2000, nbx.KERNEL_JLANE), (8192, nbx.KERNEL_JLANE), (16384, nbx.KERNEL_SGPRW), (262144, nbx.KERNEL_SGPR)):
         with nbx.Context(n, 32) as c:
             assert c.stats()["kernel_variant"] == want, n
-    with nbx.Context(2000, 64) as c:  # fp64 has no such kernel
-        assert c.stats()["kernel_variant"] == nbx.KERNEL_SGPRW
+    for n, want in ((2000, nbx.KERNEL_JLANE), (12288, nbx.KERNEL_JLANE), (16384, nbx.KERNEL_SGPRW)):  # fp64 form, same threshold
+        with nbx.Context(n, 64) as c:
+            assert c.stats()["kernel_variant"] == want, n
     # 4 logical ranks of a small system: every rank owns <= 12288 bodies, so every rank steps with one launch; bit-equal to one context
     n = 4099
     ic = nbx.initial_conditions(n)
