@@ -109,6 +109,7 @@ ForceLauncher<T> pick(int B, int variant, int epi, int loop) {
 // Does the hand-scheduled loop exist for this shape?  (mirror of kHasAsmLoop for run-time shape decisions)
 bool asm_loop_available(const nbx_ctx* c, int epi) {
   (void)epi;
+  if (c->variant == NBX_KERNEL_JLANE) return c->precision == 32 && (c->B == 2 || c->B == 4 || c->B == 8);
   if (c->variant == NBX_KERNEL_SGPRW && c->jps % 256 != 0) return false;  // a wave walks a quarter of a split: whole trips only
   return c->precision == 32 && (c->variant == NBX_KERNEL_SGPR || c->variant == NBX_KERNEL_SGPRW) && c->math == MATH_PACKED && (c->B == 2 || c->B == 4);
 }
@@ -281,10 +282,20 @@ int enqueue_force(nbx_ctx* c, int epi, double dt) {
   if (c->variant == NBX_KERNEL_JLANE) {
     if constexpr (sizeof(T) == 4) {
       const int acc_only = epi == EPI_SLAB ? 1 : 0;  // nbx_accel asks for the slab form: accelerations only
-      switch (c->B) {  // prefetch depth: enough records in flight to cover an L2 round trip with NB/2 x 56 cycles of work each
-        case 2: hipLaunchKernelGGL((force_jlane_kernel<2, 8>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only); break;
-        case 4: hipLaunchKernelGGL((force_jlane_kernel<4, 8>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only); break;
-        case 8: hipLaunchKernelGGL((force_jlane_kernel<8, 4>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only); break;
+      const bool hand = c->loop == LOOP_ASM;  // the generated main loop (NB <= 8); D = prefetch depth of the compiled loop / tail
+      switch (c->B) {
+        case 2:
+          if (hand) hipLaunchKernelGGL((force_jlane_kernel<2, 8, LOOP_ASM>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only);
+          else hipLaunchKernelGGL((force_jlane_kernel<2, 8>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only);
+          break;
+        case 4:
+          if (hand) hipLaunchKernelGGL((force_jlane_kernel<4, 8, LOOP_ASM>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only);
+          else hipLaunchKernelGGL((force_jlane_kernel<4, 8>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only);
+          break;
+        case 8:
+          if (hand) hipLaunchKernelGGL((force_jlane_kernel<8, 4, LOOP_ASM>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only);
+          else hipLaunchKernelGGL((force_jlane_kernel<8, 4>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only);
+          break;
         default: hipLaunchKernelGGL((force_jlane_kernel<16, 4>), c->grid, dim3(kBlock), 0, c->stream, a, acc_only); break;
       }
     } else {
@@ -535,7 +546,16 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
     return fail(NBX_ERR_ARG, "nbx_create: inner_loop must be NBX_LOOP_AUTO, NBX_LOOP_CXX or NBX_LOOP_ASM");
   c->loop = (o.inner_loop != NBX_LOOP_CXX && asm_loop_available(c, c->epi)) ? LOOP_ASM : LOOP_CXX;
   if (o.inner_loop == NBX_LOOP_ASM && c->loop != LOOP_ASM)
-    return fail(NBX_ERR_ARG, "nbx_create: no hand-scheduled loop for this shape (needs fp32, kernel_variant SGPR or SGPRW with j_per_split a multiple of 256, 2 or 4 bodies per lane)");
+    return fail(NBX_ERR_ARG, "nbx_create: no hand-scheduled loop for this shape (needs fp32; kernel_variant SGPR or SGPRW with j_per_split a multiple of 256 and 2 or 4 bodies per lane, or JLANE with 2, 4 or 8 bodies per wave)");
+  // The jlane kernel's generated loop keeps four records per set in flight; with few bodies per wave that is too little
+  // arithmetic to cover an L2 round trip when a SIMD holds a single wave, and the compiled loop (eight records per set) is
+  // 3-4 % ahead there (profiles/r02_jlane_ab.txt).  Auto takes the generated loop where it measured faster: 8 bodies per wave,
+  // or 4 with more than one wave per SIMD.
+  if (o.inner_loop == NBX_LOOP_AUTO && c->variant == NBX_KERNEL_JLANE && c->loop == LOOP_ASM) {
+    const int cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+    const bool several_waves = ceil_div(c->i_count, c->B) > cus * 4;
+    if (!(c->B == 8 || (c->B == 4 && several_waves))) c->loop = LOOP_CXX;
+  }
   // use_graph: 0 auto (launch-bound sizes only: < ~0.3 ms of pair work per step), 1 on, 2 off;
   // capture needs a stream of our own
   {

@@ -480,9 +480,14 @@ __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> 
 // serves the tree-order range only (n <= 131072).  acc_only != 0: store the accelerations to accp instead
 // of integrating (nbx_accel).
 // ---------------------------------------------------------------------------------------------
-template <int NB, int D>
+#include "nbx_jlane_loop.inc"
+
+// LOOP_ASM (NB = 2, 4, 8): whole trips of 8 records per lane go through the generated loop, a remainder of four records
+// through the compiled one -- the same operations in the same order either way (tests compare the bits).
+template <int NB, int D, int LOOP = LOOP_CXX>
 __global__ __launch_bounds__(kBlock, 1) void force_jlane_kernel(const ForceArgs<float> a, const int acc_only) {
   static_assert(NB % 2 == 0 && NB >= 2 && NB <= 16 && D >= 1, "two bodies per packed operation; body state must fit the SGPR file");
+  static_assert(LOOP == LOOP_CXX || NB <= 8, "the generated loop exists for 2, 4 and 8 bodies per wave");
   __shared__ float4 red[4][NB][65];  // [wave][body][lane], one float4 of padding per column: lanes t read 1040 B apart
   __shared__ double ksum[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -551,12 +556,23 @@ __global__ __launch_bounds__(kBlock, 1) void force_jlane_kernel(const ForceArgs<
       if (d < count) apply_record(r[d]);
   };
   int k = 0;
-  request(ra, 0);
-  for (; k + 2 * D <= K; k += 2 * D) {
-    request(rb, k + D);
-    apply(ra);
-    request(ra, k + 2 * D);
-    apply(rb);
+  if constexpr (LOOP == LOOP_ASM) {
+    const int trips = K >> 3;  // K is a multiple of 4: the remainder is 0 or 4 records
+    if (trips > 0) {
+      if constexpr (NB == 2) jlane_loop_asm_nb2(a.posm, trips, xi, yi, zi, ax, ay, az);
+      else if constexpr (NB == 4) jlane_loop_asm_nb4(a.posm, trips, xi, yi, zi, ax, ay, az);
+      else jlane_loop_asm_nb8(a.posm, trips, xi, yi, zi, ax, ay, az);
+      k = trips << 3;
+    }
+    if (k < K) request(ra, k);
+  } else {
+    request(ra, 0);
+    for (; k + 2 * D <= K; k += 2 * D) {
+      request(rb, k + D);
+      apply(ra);
+      request(ra, k + 2 * D);
+      apply(rb);
+    }
   }
   if (k < K) {  // fewer than 2 D records left: ra holds records k .. k + D - 1
     request(rb, k + D);

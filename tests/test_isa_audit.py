@@ -150,6 +150,12 @@ def test_generated_asm_loop_is_in_sync_with_its_generator(tmp_path):
     assert open(out).read() == open(os.path.join(ROOT, "nbody-demo-2023_amd", "csrc", "nbx_sgpr_loop.inc")).read()
 
 
+def test_generated_jlane_loop_is_in_sync_with_its_generator(tmp_path):
+    out = tmp_path / "jlane.inc"
+    subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_jlane_loop.py"), str(out)])
+    assert open(out).read() == open(os.path.join(ROOT, "nbody-demo-2023_amd", "csrc", "nbx_jlane_loop.inc")).read()
+
+
 def test_hand_scheduled_instances_have_no_scalar_moves_in_the_loop(kernels):
     seen = 0
     for name, (body, _) in kernels.items():

@@ -177,6 +177,28 @@ def test_jlane_sizes_against_the_reference_binary(nbx, name):
         assert _crc(d[f]) == g["final"][f]["crc32"], f
 
 
+@pytest.mark.parametrize("NB", [2, 4, 8])
+@pytest.mark.parametrize("n,steps", [(5, 10), (300, 30), (2000, 40), (2048, 20), (4099, 20), (8192, 10), (12288, 6), (768, 25)])
+def test_jlane_hand_scheduled_main_loop_is_bit_equal_to_the_compiled_one(nbx, n, steps, NB):
+    """Whole trips of 8 records per lane through the generated loop (nbx_jlane_loop.inc), the remainder through the compiled
+    one: same bits as the all-compiled kernel -- sizes with 0 trips (n <= 256), with and without a 4-record remainder."""
+    ic = nbx.initial_conditions(n)
+    res = []
+    for loop in (nbx.LOOP_ASM, nbx.LOOP_CXX):
+        with nbx.Context(n, 32, kernel_variant=nbx.KERNEL_JLANE, bodies_per_lane=NB, inner_loop=loop, use_graph=2) as c:
+            c.upload(ic)
+            acc = c.accel()
+            ke = c.step_trace(steps)
+            st = c.stats()
+            assert st["inner_loop"] == loop and st["kernel_variant"] == nbx.KERNEL_JLANE and st["bodies_per_lane"] == NB
+            res.append((acc, ke, c.download()))
+    for q in range(3):
+        assert np.array_equal(res[0][0][q], res[1][0][q]), q
+    assert np.array_equal(res[0][1], res[1][1])
+    for f in res[0][2]:
+        assert np.array_equal(res[0][2][f], res[1][2][f]), f
+
+
 def test_jlane_is_the_default_for_launch_bound_sizes_and_shards_like_the_others(nbx):
     for n, want in ((2000, nbx.KERNEL_JLANE), (8192, nbx.KERNEL_JLANE), (16384, nbx.KERNEL_SGPRW), (262144, nbx.KERNEL_SGPR)):
         with nbx.Context(n, 32) as c:

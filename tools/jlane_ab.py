@@ -10,7 +10,8 @@ for n in sizes:
     ref = None
     for name, kw in (("sgprw", dict(kernel_variant=nbx.KERNEL_SGPRW)), ("jlane2", dict(kernel_variant=nbx.KERNEL_JLANE, bodies_per_lane=2)),
                      ("jlane4", dict(kernel_variant=nbx.KERNEL_JLANE, bodies_per_lane=4)), ("jlane8", dict(kernel_variant=nbx.KERNEL_JLANE, bodies_per_lane=8)),
-                     ("jlane16", dict(kernel_variant=nbx.KERNEL_JLANE, bodies_per_lane=16)), ("auto", dict())):
+                     ("jlane16", dict(kernel_variant=nbx.KERNEL_JLANE, bodies_per_lane=16)), ("auto", dict()),
+                     ("auto/cxx", dict(inner_loop=nbx.LOOP_CXX))):
         if name.startswith("jlane") and n / int(name[5:]) > 16384:
             continue
         with nbx.Context(n, 32, **kw) as c:
