@@ -276,6 +276,7 @@ def main():
         pairs_per_step = float(n) * float(n)
         value = pairs_per_step * a.steps / elapsed
         peak = PEAK_FP32_VECTOR_TFLOPS if a.precision == 32 else PEAK_FP64_VECTOR_TFLOPS
+        mix_ceiling = 0.625 if a.precision == 32 else 1280.0 / (76 * 32)
         launch_ms = st["force_ms_total"] / max(1, st["force_launches_timed"])
         achieved = FLOP_PER_PAIR * st["pairs_per_launch"] / (launch_ms * 1e-3) * 1e-12 if launch_ms > 0 else 0.0
         # algorithmic HBM bytes of ONE force launch of the shape that ran: every record once, plus the owned
@@ -322,6 +323,10 @@ def main():
                          "algorithmic_bytes": alg_bytes, "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                          "algorithmic_GBps": alg_bytes / (launch_ms * 1e-3) * 1e-9 if launch_ms > 0 else None,
                          "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": st["pairs_per_launch"],
+                         # the most this instruction mix can reach at the spec clock: fp32 12 packed
+                         # ops + 2 quarter-rate v_rsq_f32 per 2 pairs = 64 issue cycles for 40 of 64 creditable flop/cycle;
+                         # fp64 15 ops + one 16-cycle v_rsq_f64 per pair
+                         "mix_ceiling_frac": mix_ceiling, "frac_of_mix_ceiling": achieved / peak / mix_ceiling,
                          "launch_ms_avg": launch_ms, "launches_timed": st["force_launches_timed"],
                          "note": "fp%d vector FMA roofline (north_star: FMA/rsqrt-bound, no MFMA); for fp32 the 157.3 "
                                  "TFLOP/s is also the dense f32 MFMA peak.  HBM is not the bound: see DESIGN.md" % a.precision},
