@@ -268,7 +268,7 @@ def main():
                  "force_kernel_ms": st8["force_ms_total"] / max(1, st8["force_launches_timed"]),
                  "roofline_frac": FLOP_PER_PAIR * 131072.0 * 1048576.0 / t_rank / (PEAK_FP32_VECTOR_TFLOPS * 1e12),
                  "bodies_per_lane": st8["bodies_per_lane"], "grid": [st8["force_grid_x"], st8["force_grid_y"]],
-                 "inner_loop": {1: "cxx", 2: "asm"}.get(st8["inner_loop"], "?"),
+                 "inner_loop": {1: "cxx", 2: "asm", 3: "asm_ts"}.get(st8["inner_loop"], "?"),
                  "implied_8gpu_speedup_before_communication": t_big / t_rank,
                  "note": "measured on ONE GPU with a 131072-body slice; not an 8-GPU measurement"}
 
@@ -310,7 +310,7 @@ def main():
                        "bodies_per_lane": st["bodies_per_lane"], "j_split": st["j_split"],
                        "summation_order": {1: "reference", 2: "tree"}.get(st["summation_order"], "?"),
                        "kernel": {1: "lds", 2: "sgpr", 3: "sgprw", 4: "exact", 6: "jlane"}.get(st["kernel_variant"], "?"),
-                       "inner_loop": {1: "compiler-scheduled", 2: "hand-scheduled asm"}.get(st["inner_loop"], "?"),
+                       "inner_loop": {1: "compiler-scheduled", 2: "hand-scheduled asm", 3: "hand-scheduled asm, time-sliced wave priority"}.get(st["inner_loop"], "?"),
                        "grid": [st["force_grid_x"], st["force_grid_y"]], "block": st["force_block"]},
             "gflops_reference_convention": 1e-9 * (29.0 * pairs_per_step + 19.0 * n) * a.steps / elapsed,
             "kenergy_after_run": ke,

@@ -38,7 +38,7 @@ enum {
 };
 
 enum { NBX_ORDER_AUTO = 0, NBX_ORDER_REFERENCE = 1, NBX_ORDER_TREE = 2 };
-enum { NBX_LOOP_AUTO = 0, NBX_LOOP_CXX = 1, NBX_LOOP_ASM = 2 };
+enum { NBX_LOOP_AUTO = 0, NBX_LOOP_CXX = 1, NBX_LOOP_ASM = 2, NBX_LOOP_ASM_TS = 3 };
 
 /* kernel_variant values */
 enum {
@@ -96,8 +96,11 @@ typedef struct nbx_opts {
                                   (its summation noise is ~1e-13, far inside the 1e-10 gate either way) */
   int32_t inner_loop;      /* scheduling of the SGPR kernel's j loop: 0 = NBX_LOOP_AUTO (the hand-scheduled gfx950 loop wherever
                               an instance exists: packed fp32, kernel_variant SGPR or SGPRW, 2 or 4 bodies per lane, whole trips per wave), 1 = NBX_LOOP_CXX
-                              (always the compiler-scheduled C++ loop), 2 = NBX_LOOP_ASM (fail if no instance fits the shape).
-                              Both loops perform the same operations in the same order: results are bit-identical */
+                              (always the compiler-scheduled C++ loop), 2 = NBX_LOOP_ASM (fail if no instance fits the shape),
+                              3 = NBX_LOOP_ASM_TS (the hand-scheduled loop with time-sliced wave priority: the waves sharing a SIMD
+                              take turns as the favoured one instead of running one after the other; single-row SGPR kernel only --
+                              AUTO takes it there when the fullest CU holds exactly two workgroups, where it measured +3 ... +4.5 %).  All loops perform the same operations in
+                              the same order: results are bit-identical */
   int32_t reserved[2];
 } nbx_opts;
 
@@ -115,7 +118,7 @@ typedef struct nbx_stats_t {
   char    device_name[64];
   int64_t graph_replays;       /* hipGraph launches issued by nbx_step (each covers up to 50 steps) */
   int32_t use_graph;           /* 1 if nbx_step replays windows from a hipGraph */
-  int32_t inner_loop;          /* NBX_LOOP_CXX or NBX_LOOP_ASM actually in use by the step kernel */
+  int32_t inner_loop;          /* NBX_LOOP_CXX, NBX_LOOP_ASM or NBX_LOOP_ASM_TS actually in use by the step kernel */
 } nbx_stats_t;
 
 /* Text of the last error on the calling thread ("" if none). Never NULL. */

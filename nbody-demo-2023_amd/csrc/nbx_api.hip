@@ -64,12 +64,20 @@ using ForceLauncher = void (*)(const ForceArgs<T>&, dim3, hipStream_t);
 template <typename T, int JSRC, int EPI, int MATH, bool WS>
 ForceLauncher<T> pick_b(int B, int loop) {
   if constexpr (kHasAsmLoop<T, JSRC, EPI, MATH, WS>) {
+    if constexpr (!WS && EPI == EPI_ROW) {  // time-sliced priority: the whole-launch-resident reference-order shapes only
+      if (loop == LOOP_ASM_TS) {
+        if (B == 2) return launch_force_t<T, 2, JSRC, EPI, MATH, WS, LOOP_ASM_TS>;
+        if (B == 4) return launch_force_t<T, 4, JSRC, EPI, MATH, WS, LOOP_ASM_TS>;
+        return nullptr;
+      }
+    }
+    if (loop == LOOP_ASM_TS) loop = LOOP_ASM;  // e.g. nbx_accel's slab form of a time-sliced context
     if (loop == LOOP_ASM) {
       if (B == 2) return launch_force_t<T, 2, JSRC, EPI, MATH, WS, LOOP_ASM>;
       if (B == 4) return launch_force_t<T, 4, JSRC, EPI, MATH, WS, LOOP_ASM>;
       return nullptr;
     }
-  } else if (loop == LOOP_ASM) {
+  } else if (loop != LOOP_CXX) {
     return nullptr;
   }
   switch (B) {
@@ -117,7 +125,7 @@ bool asm_loop_available(const nbx_ctx* c, int epi) {
 template <typename T>
 ForceLauncher<T> pick_force(const nbx_ctx* c, int epi) {
   // nbx_accel runs the EPI_SLAB form of a context whose step kernel may be another epilogue: decide per call
-  const int loop = (c->loop == LOOP_ASM && asm_loop_available(c, epi)) ? LOOP_ASM : LOOP_CXX;
+  const int loop = (c->loop != LOOP_CXX && asm_loop_available(c, epi)) ? c->loop : LOOP_CXX;
   if constexpr (sizeof(T) == 4) {
     if (c->math == MATH_PACKED) return pick<float, MATH_PACKED>(c->B, c->variant, epi, loop);
   }
@@ -277,6 +285,7 @@ int enqueue_force(nbx_ctx* c, int epi, double dt) {
   a.j_per_split = c->jps;
   a.n_alloc = c->n_alloc;
   a.dt = (T)dt;
+  a.slice_bit = c->slice_bit;
   const bool prof = c->profiling && c->ev_used + 2 <= c->ev.size();
   if (prof) HIP_TRY(hipEventRecord(c->ev[c->ev_used], c->stream));
   if (c->variant == NBX_KERNEL_JLANE) {
@@ -542,11 +551,28 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
     c->own_stream = true;
   }
   auto_shape(c, o);
-  if (o.inner_loop != NBX_LOOP_AUTO && o.inner_loop != NBX_LOOP_CXX && o.inner_loop != NBX_LOOP_ASM)
-    return fail(NBX_ERR_ARG, "nbx_create: inner_loop must be NBX_LOOP_AUTO, NBX_LOOP_CXX or NBX_LOOP_ASM");
+  if (o.inner_loop != NBX_LOOP_AUTO && o.inner_loop != NBX_LOOP_CXX && o.inner_loop != NBX_LOOP_ASM && o.inner_loop != NBX_LOOP_ASM_TS)
+    return fail(NBX_ERR_ARG, "nbx_create: inner_loop must be NBX_LOOP_AUTO, NBX_LOOP_CXX, NBX_LOOP_ASM or NBX_LOOP_ASM_TS");
   c->loop = (o.inner_loop != NBX_LOOP_CXX && asm_loop_available(c, c->epi)) ? LOOP_ASM : LOOP_CXX;
-  if (o.inner_loop == NBX_LOOP_ASM && c->loop != LOOP_ASM)
+  if ((o.inner_loop == NBX_LOOP_ASM || o.inner_loop == NBX_LOOP_ASM_TS) && c->loop != LOOP_ASM)
     return fail(NBX_ERR_ARG, "nbx_create: no hand-scheduled loop for this shape (needs fp32; kernel_variant SGPR or SGPRW with j_per_split a multiple of 256 and 2 or 4 bodies per lane, or JLANE with 2, 4 or 8 bodies per wave)");
+  // Time-sliced wave priority (LOOP_ASM_TS) exists for the row-epilogue SGPR kernel: one workgroup row, every wave resident
+  // from the first cycle to the last.  Auto takes it when the fullest CU holds exactly two workgroups, i.e. two waves per
+  // SIMD: measured +4.5 % at 512 workgroups, +2.7 % at 384, -0.6 % with one wave per SIMD (nobody to alternate with, six
+  // more scalar instructions per trip) and -0.6 ... +0.3 % with three, four or eight (profiles/r02_time_sliced_ab.txt).
+  {
+    const bool ts_shape = c->loop == LOOP_ASM && c->variant == NBX_KERNEL_SGPR && c->epi == EPI_ROW;
+    if (o.inner_loop == NBX_LOOP_ASM_TS && !ts_shape)
+      return fail(NBX_ERR_ARG, "nbx_create: NBX_LOOP_ASM_TS needs the single-row SGPR kernel (reference summation order or j_split 1, fp32, 2 or 4 bodies per lane)");
+    const int cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+    const bool two_per_simd = (int)c->grid.x > cus && (int)c->grid.x <= 2 * cus;
+    if (ts_shape && (o.inner_loop == NBX_LOOP_ASM_TS || (o.inner_loop == NBX_LOOP_AUTO && two_per_simd))) c->loop = LOOP_ASM_TS;
+  }
+  c->slice_bit = kSliceBit;
+  if (const char* e = getenv("NBX_SLICE_BIT")) {  // experiments: log2 of the slice length in 10 ns units
+    const int k = atoi(e);
+    if (k >= 4 && k <= 30) c->slice_bit = 1u << k;
+  }
   // The jlane kernel's generated loop keeps four records per set in flight; with few bodies per wave that is too little
   // arithmetic to cover an L2 round trip when a SIMD holds a single wave, and the compiled loop (eight records per set) is
   // 3-4 % ahead there (profiles/r02_jlane_ab.txt).  Auto takes the generated loop where it measured faster: 8 bodies per wave,
@@ -833,7 +859,7 @@ int nbx_stats(nbx_ctx* c, nbx_stats_t* s) {
   s->pairs_per_launch = (double)c->i_count * (double)c->n;
   s->graph_replays = c->graph_replays;
   s->use_graph = c->use_graph ? 1 : 0;
-  s->inner_loop = c->loop == LOOP_ASM ? NBX_LOOP_ASM : NBX_LOOP_CXX;
+  s->inner_loop = c->loop == LOOP_ASM_TS ? NBX_LOOP_ASM_TS : c->loop == LOOP_ASM ? NBX_LOOP_ASM : NBX_LOOP_CXX;
   // some boxes report an empty marketing name; fall back to / append the ISA name
   std::snprintf(s->device_name, sizeof(s->device_name), "%s%s%s", c->prop.name, c->prop.name[0] ? " " : "",
                 c->prop.gcnArchName);

@@ -49,7 +49,8 @@ inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 struct nbx_ctx {
   int n = 0, n_alloc = 0, i_begin = 0, i_count = 0, own_pad = 0, precision = 32;
   int B = 1, S = 1, jps = 0, variant = NBX_KERNEL_LDS, epi = 0 /* nbx::EPI_SLAB */, math = 0 /* nbx::MATH_SCALAR */, order = NBX_ORDER_TREE;
-  int loop = 0;  // nbx::LOOP_CXX; nbx::LOOP_ASM where the hand-scheduled j loop is in use
+  int loop = 0;  // nbx::LOOP_CXX; nbx::LOOP_ASM where the hand-scheduled j loop is in use; nbx::LOOP_ASM_TS with time-sliced wave priority
+  unsigned slice_bit = 0;  // LOOP_ASM_TS: clock bit of the priority slices
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;

@@ -189,6 +189,7 @@ struct ForceArgs {
                                      // LDS source, of 4*kSgprBatch (2*kSgprBatch per wave under WSPLIT) for the SGPR one
   int n_alloc;                       // multiple of kTile
   T dt;
+  unsigned slice_bit;                // LOOP_ASM_TS: clock bit of the priority slices (kSliceBit unless NBX_SLICE_BIT overrides)
 };
 
 enum : int { JSRC_LDS = 1, JSRC_SGPR = 2 };
@@ -241,7 +242,16 @@ enum : int { MATH_SCALAR = 0, MATH_PACKED = 1 };
 // gfx950 loop of nbx_sgpr_loop.inc (packed fp32, B = 2 or 4, no wave split): same operations in the same order, hence
 // the same bits (tests compare the two), but no s_mov splats, one pointer update per trip and 8-byte aligned VOP3P code:
 // worth 13 % when a SIMD holds a single wave, where every scalar instruction costs a full 4-cycle issue slot.
-enum : int { LOOP_CXX = 0, LOOP_ASM = 1 };
+// LOOP_ASM_TS = the same loop with time-sliced wave priority, for shapes that put two waves on a SIMD for the whole launch
+// (reference order, grid.y == 1, 257..512 workgroups on 256 CUs): this chip issues the waves of a SIMD in strict age order,
+// so without it they run one after the other -- the older one leaves the loop at 0.50 of the kernel time -- and the younger
+// one has nobody to fill its issue bubbles (tools/wave_fair.hip).  +4.5 % at n = 262144; nothing to gain
+// with one wave per SIMD (-0.6 %: the six scalar instructions) or with three and more (profiles/r02_time_sliced_ab.txt).
+enum : int { LOOP_CXX = 0, LOOP_ASM = 1, LOOP_ASM_TS = 2 };
+// clock bit (s_memrealtime counts 10 ns) that selects the favoured slot parity: slices of 2^16 x 10 ns = 0.66 ms.  Measured
+// 2^14 ... 2^19 within 1 % of each other, 2^16-2^17 best; shorter slices lose to the time the unfavoured wave needs to reach
+// its next decision, longer ones to the imbalance of the last slice.
+constexpr unsigned kSliceBit = 1u << 16;
 #include "nbx_sgpr_loop.inc"
 // What a workgroup does with its accelerations:
 //   EPI_SLAB  write them to its split's slab (the separate integrate_kernel, or nbx_accel, consumes the slabs)
@@ -286,6 +296,12 @@ struct IBodies<float, B, MATH_PACKED> {
     static_assert(B == 2 || B == 4, "the asm loop exists for 2 and 4 bodies per lane");
     if constexpr (B == 2) sgpr_loop_asm_b2(first, last, xi[0], yi[0], zi[0], ax[0], ay[0], az[0]);
     else sgpr_loop_asm_b4(first, last, xi[0], yi[0], zi[0], xi[1], yi[1], zi[1], ax[0], ay[0], az[0], ax[1], ay[1], az[1]);
+  }
+  // the same with time-sliced wave priority (LOOP_ASM_TS); slot_bit = slice_bit for waves in odd slots of their SIMD, else 0
+  __device__ __forceinline__ void apply_range_asm_ts(const float4* first, const float4* last, unsigned slice_bit, unsigned slot_bit) {
+    static_assert(B == 2 || B == 4, "the asm loop exists for 2 and 4 bodies per lane");
+    if constexpr (B == 2) sgpr_loop_asm_b2_ts(first, last, slice_bit, slot_bit, xi[0], yi[0], zi[0], ax[0], ay[0], az[0]);
+    else sgpr_loop_asm_b4_ts(first, last, slice_bit, slot_bit, xi[0], yi[0], zi[0], xi[1], yi[1], zi[1], ax[0], ay[0], az[0], ax[1], ay[1], az[1]);
   }
 };
 
@@ -352,6 +368,14 @@ __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> 
     // j range = a positive multiple of kSgprAsmTrip<B> records (the host rounds j_per_split to 64, to 256 under WSPLIT where a
     // wave walks a quarter of it; n_alloc is a multiple of 256)
     if (j0 < j1) ib.apply_range_asm(a.posm + j0, a.posm + j1);
+  } else if constexpr (LOOP == LOOP_ASM_TS) {
+    if (j0 < j1) {
+      unsigned hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));  // bits 3:0 = the wave's slot on its SIMD
+      const unsigned slice = __builtin_amdgcn_readfirstlane(a.slice_bit);
+      ib.apply_range_asm_ts(a.posm + j0, a.posm + j1, slice, (hwid & 1u) ? slice : 0u);
+      __builtin_amdgcn_s_setprio(0);
+    }
   } else {
     // Wave-uniform j index => the records travel by s_load_dwordx16 (64 B = kSgprBatch records) into
     // SGPRs and feed the VALU as scalar operands: no LDS bandwidth, no VGPRs, no barrier.  Two

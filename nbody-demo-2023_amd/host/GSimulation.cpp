@@ -237,9 +237,11 @@ void GSimulation::start() {
   if (kv && !std::strcmp(kv, "jlane")) opts.kernel_variant = NBX_KERNEL_JLANE;
   if (kv && !std::strcmp(kv, "exact")) opts.kernel_variant = NBX_KERNEL_EXACT;  // bit-for-bit the CPU ver7 arithmetic
 
-  // NBODY_LOOP=asm|cxx: the hand-scheduled j loop (default wherever it exists) or the compiler-scheduled one -- same bits
+  // NBODY_LOOP=asm|asm_ts|cxx: the hand-scheduled j loop (default wherever it exists; asm_ts = with time-sliced wave
+  // priority, the default where a SIMD holds several reference-order waves) or the compiler-scheduled one -- same bits
   if (const char* lp = std::getenv("NBODY_LOOP")) {
     if (!std::strcmp(lp, "asm")) opts.inner_loop = NBX_LOOP_ASM;
+    if (!std::strcmp(lp, "asm_ts")) opts.inner_loop = NBX_LOOP_ASM_TS;
     if (!std::strcmp(lp, "cxx")) opts.inner_loop = NBX_LOOP_CXX;
   }
   // NBODY_ORDER=reference|tree: how each body's pair terms are summed (include/nbx.h summation_order); default auto
@@ -373,7 +375,7 @@ void GSimulation::start() {
   std::cout << "# Device             : " << st.device_name << " (" << st.cu_count << " CUs), fp" << st.precision
             << ", kernel " << kernel_name(st.kernel_variant)
             << ", " << (st.summation_order == NBX_ORDER_REFERENCE ? "reference-order" : "tree") << " sums"
-            << (st.inner_loop == NBX_LOOP_ASM ? " (hand-scheduled loop)" : "") << ", bodies/lane " << st.bodies_per_lane << ", j-split " << st.j_split << ", grid " << st.force_grid_x << "x"
+            << (st.inner_loop == NBX_LOOP_ASM ? " (hand-scheduled loop)" : st.inner_loop == NBX_LOOP_ASM_TS ? " (hand-scheduled loop, time-sliced wave priority)" : "") << ", bodies/lane " << st.bodies_per_lane << ", j-split " << st.j_split << ", grid " << st.force_grid_x << "x"
             << st.force_grid_y << std::endl;
   if (ranks > 1 || _multiprocess)
     std::cout << "# GPUs / ranks       : " << ranks << " x " << st.i_count << " bodies" << (_multiprocess ? " (one process per rank)" : "")

@@ -47,7 +47,7 @@ def time_steps(n, precision, target_s=1.0, order=0):
             "force_kernel_us": 1e3 * kms, "force_kernel_frac": 20.0 * float(n) * n / (kms * 1e-3) / PEAK[precision] if kms else None,
             "bodies_per_lane": st["bodies_per_lane"], "j_split": st["j_split"], "grid": [st["force_grid_x"], st["force_grid_y"]],
             "kernel": {1: "lds", 2: "sgpr", 3: "sgprw", 6: "jlane"}[st["kernel_variant"]], "graph_replay": bool(st["use_graph"]),
-            "inner_loop": {1: "cxx", 2: "asm"}.get(st["inner_loop"], "?"),
+            "inner_loop": {1: "cxx", 2: "asm", 3: "asm_ts"}.get(st["inner_loop"], "?"),
             "order": {1: "reference", 2: "tree"}[st["summation_order"]]}
 
 
@@ -66,7 +66,7 @@ def main():
         rows.append(r)
         print("%9d %8d %12.1f %14.1f %9.2f %12.1f %9.2f  %s %s%s B%d S%d %dx%d" % (
             r["n"], r["steps"], r["us_per_step"], r["pair_per_s"] * 1e-9, 100 * r["roofline_frac"], r["force_kernel_us"],
-            100 * (r["force_kernel_frac"] or 0), r["order"], r["kernel"], "/asm" if r["inner_loop"] == "asm" else "", r["bodies_per_lane"], r["j_split"],
+            100 * (r["force_kernel_frac"] or 0), r["order"], r["kernel"], ("/" + r["inner_loop"]) if r["inner_loop"] in ("asm", "asm_ts") else "", r["bodies_per_lane"], r["j_split"],
             r["grid"][0], r["grid"][1]), flush=True)
         n *= 2
     os.makedirs(os.path.dirname(a.out), exist_ok=True)

@@ -167,3 +167,25 @@ def test_hand_scheduled_instances_have_no_scalar_moves_in_the_loop(kernels):
         assert "s_mov_b32" not in loop and "s_mov_b64" not in loop, name
         assert loop.count("s_load_dwordx16") in (8, 16) and loop.count("v_rsq_f32") == 128, name  # 32 / 64 records per trip
     assert seen == 6, seen  # B in {2, 4} x {row, slab} without wave split, x {slab} with
+
+
+def test_time_sliced_instances_set_priority_once_per_trip(kernels):
+    """LOOP_ASM_TS (the last template argument = 2): row epilogue, no wave split, B = 2 and 4.  The loop is the plain one plus one
+    clock read, the two-instruction decision, the s_setprio pair around a forward branch -- and nothing else that is scalar."""
+    seen = 0
+    for name, (body, _) in kernels.items():
+        if not re.search(r"force_kernelIfLi[24]ELi2ELi1ELi1ELi1ELb0ELi2E", name):
+            continue
+        seen += 1
+        assert body.count("s_getreg_b32") == 1, name
+        asms = [m.group(0) for m in re.finditer(r"#ASMSTART.*?#ASMEND", body, re.S)]
+        loop = [a for a in asms if "s_memrealtime" in a]
+        assert len(loop) == 1, name
+        loop = loop[0][loop[0].index("1:"):]
+        assert loop.count("s_memrealtime") == 1 and loop.count("s_setprio 0") == 1 and loop.count("s_setprio 3") == 1, name
+        assert loop.count("s_cbranch_scc0 2f") == 1 and loop.count("s_cbranch_scc1 1b") == 1, name
+        assert "s_mov_b32" not in loop and "s_mov_b64" not in loop, name
+        assert loop.count("s_load_dwordx16") in (8, 16) and loop.count("v_rsq_f32") == 128, name
+        # the wave returns to priority 0 behind the loop (the epilogue and the next kernel start level)
+        assert "s_setprio 0" in body[body.rindex("#ASMEND"):], name
+    assert seen == 2, seen

@@ -1278,10 +1278,66 @@ def test_hand_scheduled_loop_bit_equal_over_random_sizes_slices_and_splits(nbx):
     assert checked >= 40, checked
 
 
+@pytest.mark.parametrize("n,own,steps,B", [(262144, 262144, 2, 2), (262144, 262144, 1, 4), (131072, 131072, 3, 2), (16384, 16384, 12, 2),
+                                            (4099, 4099, 25, 4), (524288, 65536, 1, 2)])
+def test_time_sliced_wave_priority_changes_no_bit(nbx, n, own, steps, B):
+    """NBX_LOOP_ASM_TS = the hand-scheduled loop plus, once per trip, an s_setprio decided by the clock and the wave's slot
+    on its SIMD.  Priority only changes WHEN a wave issues, never what it computes: accelerations, trajectories and energies
+    equal those of the plain asm loop and of the compiled loop bit for bit -- with two waves per SIMD (n = 262144, B = 2: 512
+    workgroups), with one (262144 x B4, 131072 x B2: 256 workgroups), on small grids and on a slice of a larger system."""
+    ic = nbx.initial_conditions(n)
+    res = []
+    for loop in (nbx.LOOP_ASM_TS, nbx.LOOP_ASM, nbx.LOOP_CXX):
+        with nbx.Context(n, 32, kernel_variant=nbx.KERNEL_SGPR, bodies_per_lane=B, inner_loop=loop, use_graph=2, j_split=1,
+                         i_begin=0, i_count=own, n_alloc=n) as c:
+            c.upload(ic)
+            acc = c.accel()
+            for _ in range(steps):
+                c.step_local()
+                c.commit()
+            part = c.kenergy_partial()
+            st = c.stats()
+            assert st["inner_loop"] == loop and st["bodies_per_lane"] == B and st["force_grid_y"] == 1
+            res.append((acc, c.download(), part))
+    for other in (1, 2):
+        for k in range(3):
+            assert np.array_equal(res[0][0][k], res[other][0][k]), (other, "acc", k)
+        for f in res[0][1]:
+            assert np.array_equal(res[0][1][f], res[other][1][f]), (other, f)
+        assert res[0][2] == res[other][2], other
+
+
+def test_time_sliced_priority_with_every_slice_length(nbx, monkeypatch):
+    """NBX_SLICE_BIT picks the clock bit of the slices (experiments); from 160 ns to 10 s per slice the bits stay the same."""
+    n = 65536
+    ic = nbx.initial_conditions(n)
+    ref = None
+    for k in (None, 4, 10, 20, 30):
+        if k is None:
+            monkeypatch.delenv("NBX_SLICE_BIT", raising=False)
+        else:
+            monkeypatch.setenv("NBX_SLICE_BIT", str(k))
+        with nbx.Context(n, 32, kernel_variant=nbx.KERNEL_SGPR, bodies_per_lane=2, inner_loop=nbx.LOOP_ASM_TS, j_split=1) as c:
+            c.upload(ic)
+            ke = c.step_trace(3)
+            got = c.download()
+        if ref is None:
+            ref = (ke, got)
+        else:
+            assert np.array_equal(ke, ref[0])
+            for f in got:
+                assert np.array_equal(got[f], ref[1][f]), (k, f)
+
+
 def test_hand_scheduled_loop_is_the_default_where_it_exists(nbx):
-    with nbx.Context(262144, 32) as c:  # configs[2]: reference order, SGPR kernel, packed math
+    with nbx.Context(262144, 32) as c:  # configs[2]: reference order, SGPR kernel, packed math, two waves per SIMD
+        st = c.stats()
+        assert st["summation_order"] == nbx.ORDER_REFERENCE and st["inner_loop"] == nbx.LOOP_ASM_TS
+    with nbx.Context(1048576, 32, i_begin=0, i_count=131072, n_alloc=1048576) as c:  # one rank of eight: one wave per SIMD
         st = c.stats()
         assert st["summation_order"] == nbx.ORDER_REFERENCE and st["inner_loop"] == nbx.LOOP_ASM
+    with pytest.raises(nbx.NbxError):
+        nbx.Context(65536, 32, kernel_variant=nbx.KERNEL_SGPRW, inner_loop=nbx.LOOP_ASM_TS)  # single-row SGPR kernel only
     with nbx.Context(65536, 32) as c:  # tree order, wave-split kernel: 2048 records per split
         st = c.stats()
         assert st["kernel_variant"] == nbx.KERNEL_SGPRW and st["inner_loop"] == nbx.LOOP_ASM

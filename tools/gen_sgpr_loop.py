@@ -19,6 +19,14 @@ result; nothing is inserted inside an asm statement, so the order below IS the g
 Register plan (explicit, all clobbered):  temporaries v[T:T+23] = two slots x {dx dy dz r2 q s};  j ring
 s[36:67] (group A: 8 records) and s[68:99] (group B);  s[30:31] = pointer (biased by -TRIP bytes so every immediate
 offset is positive), s[28:29] = end value of that pointer, s[34] = softening.
+
+Time-sliced variants (sgpr_loop_asm_b*_ts, LOOP_ASM_TS): waves that share a SIMD issue in strict age order on this chip
+(tools/wave_fair.hip: of two resident waves the older one leaves the loop at 0.50 of the kernel time, the younger runs
+alone afterwards with nobody to fill its issue bubbles).  Once per trip the wave reads the 100 MHz clock
+(s_memrealtime, requested with the trip's first loads, landed by the wait that is there anyway) and takes priority 3
+when (clock & slice_bit) equals the parity of its wave slot, priority 0 otherwise: each of two waves is the favoured one
+half of the time, both stay resident to the end and fill each other's bubbles.  Six more scalar instructions per trip;
+the arithmetic is untouched (same bits).  s[26:27] = clock.
 """
 import os
 import sys
@@ -93,8 +101,12 @@ def loads(ring, off):
 WAIT = "s_waitcnt lgkmcnt(0)"
 
 
-def loop_text(B, groups_per_trip):
-    """groups_per_trip even; a trip covers 8*groups_per_trip records = trip_bytes of the record array."""
+STIME = 26
+
+
+def loop_text(B, groups_per_trip, ts=False):
+    """groups_per_trip even; a trip covers 8*groups_per_trip records = trip_bytes of the record array.
+    ts: once per trip, wave priority from the clock (operands %MASK = slice bit, %PAR = that bit if the wave's slot is odd)."""
     assert groups_per_trip % 2 == 0 and groups_per_trip >= 2
     trip = 128 * groups_per_trip
     pro = ["s_mov_b64 s[%d:%d], %%%d" % (SP, SP + 1, 6 if B == 2 else 12),
@@ -106,11 +118,20 @@ def loop_text(B, groups_per_trip):
     body = []
     # group 0 (ring A) is resident at the loop head; group g+1 is requested before group g is consumed
     body += loads(RING_B, trip + 128)
+    if ts:
+        body += ["s_memrealtime s[%d:%d]" % (STIME, STIME + 1)]
     body += group_ops(B, RING_A)
-    # four 4-byte instructions together keep the 8-byte alignment of what follows; no scalar load is in flight
-    # while the pointer changes, and SCC (set by the compare) is not written again before the branch
-    body += [WAIT, "s_add_u32 s%d, s%d, s%d" % (SP, SP, SEPS + 1), "s_addc_u32 s%d, s%d, 0" % (SP + 1, SP + 1),
-             "s_cmp_lg_u64 s[%d:%d], s[%d:%d]" % (SP, SP + 1, SE, SE + 1)]
+    # 4-byte instructions in even numbers keep the 8-byte alignment of what follows; no scalar load is in flight while the
+    # pointer changes, and SCC (set by the last compare) is not written again before the branch
+    cluster = [WAIT]
+    if ts:
+        # favoured (SCC = 1): priority 3; otherwise the branch skips the second s_setprio
+        n0 = 8 if B == 2 else 14
+        cluster += ["s_and_b32 s%d, s%d, %%%d" % (STIME, STIME, n0), "s_cmp_eq_u32 s%d, %%%d" % (STIME, n0 + 1),
+                    "s_setprio 0", "s_cbranch_scc0 2f", "s_setprio 3", "2:", "s_nop 0"]
+    cluster += ["s_add_u32 s%d, s%d, s%d" % (SP, SP, SEPS + 1), "s_addc_u32 s%d, s%d, 0" % (SP + 1, SP + 1),
+                "s_cmp_lg_u64 s[%d:%d], s[%d:%d]" % (SP, SP + 1, SE, SE + 1)]
+    body += cluster
     # from here on the pointer has advanced by one trip: offsets are relative to the NEW value
     rings = (RING_A, RING_B)
     for g in range(1, groups_per_trip):
@@ -126,7 +147,10 @@ def check_alignment(body):
     off = 0
     for ins in body:
         op = ins.split()[0]
-        size = 4 if (op in ("s_waitcnt", "s_add_u32", "s_addc_u32", "s_cmp_lg_u64", "s_cbranch_scc1", "s_nop") or op.endswith("_e32")) else 8
+        if op.endswith(":"):
+            continue
+        size = 4 if (op in ("s_waitcnt", "s_add_u32", "s_addc_u32", "s_cmp_lg_u64", "s_cbranch_scc1", "s_nop", "s_and_b32", "s_cmp_eq_u32",
+                            "s_setprio", "s_cbranch_scc0") or op.endswith("_e32")) else 8
         assert size == 4 or off % 8 == 0, (ins, off)
         off += size
     return off
@@ -155,35 +179,44 @@ def check_distance(body):
         prev_defs = set(dst)
 
 
-def emit(B, groups_per_trip):
-    pro, body, trip = loop_text(B, groups_per_trip)
+def emit(B, groups_per_trip, ts=False):
+    pro, body, trip = loop_text(B, groups_per_trip, ts)
     nbytes = check_alignment(body)
     check_distance(body)
-    lines = ['      "%s\\n"' % s for s in pro] + ['      ".p2align 3\\n"', '      "1:\\n"'] + ['      "%s\\n"' % s for s in body]
-    clob = ['"v%d"' % r for r in range(TBASE, TBASE + 24)] + ['"s%d"' % r for r in range(28, 100) if r not in (32, 33)] + ['"scc"', '"memory"']
+    lines = ['      "%s\\n"' % s for s in pro] + ['      ".p2align 3\\n"', '      "1:\\n"'] + ['      "%s\\n"' % s for s in body]  # labels ("2:") included
+    clob = (['"v%d"' % r for r in range(TBASE, TBASE + 24)] + ['"s%d"' % r for r in range(STIME if ts else 28, 100) if r not in (32, 33)] +
+            ['"scc"', '"memory"'])
     nv = sum(1 for s in body if s.startswith("v_"))
-    ns = len(body) - nv
+    ns = sum(1 for s in body if not s.startswith("v_") and not s.endswith(":"))
     if B == 2:
         sig = "f32x2 xi, f32x2 yi, f32x2 zi, f32x2& ax, f32x2& ay, f32x2& az"
         outs = '"+v"(ax), "+v"(ay), "+v"(az)'
         ins = '"v"(xi), "v"(yi), "v"(zi), "s"(q), "s"(qend)'
+        extra = ', "s"(slice_bit), "s"(slot_bit)'
     else:
         sig = ("f32x2 xi0, f32x2 yi0, f32x2 zi0, f32x2 xi1, f32x2 yi1, f32x2 zi1, f32x2& ax0, f32x2& ay0, f32x2& az0, "
                "f32x2& ax1, f32x2& ay1, f32x2& az1")
         outs = '"+v"(ax0), "+v"(ay0), "+v"(az0), "+v"(ax1), "+v"(ay1), "+v"(az1)'
         ins = '"v"(xi0), "v"(yi0), "v"(zi0), "v"(xi1), "v"(yi1), "v"(zi1), "s"(q), "s"(qend)'
+        extra = ', "s"(slice_bit), "s"(slot_bit)'
     txt = []
-    txt.append("// B = %d bodies per lane: %d records per trip, %d VALU + %d scalar instructions, %d bytes of loop body." % (B, trip // 16, nv, ns, nbytes))
+    txt.append("// B = %d bodies per lane%s: %d records per trip, %d VALU + %d scalar instructions, %d bytes of loop body." %
+               (B, ", time-sliced wave priority" if ts else "", trip // 16, nv, ns, nbytes))
     txt.append("// `first` points at the first record of the j range, `last` one past it; the range is a positive multiple of")
     txt.append("// kSgprAsmTrip<%d> records.  The final trip requests 8 records past `last` (never used; kSgprOverread spare)." % B)
-    txt.append("template <> constexpr int kSgprAsmTrip<%d> = %d;" % (B, trip // 16))
-    txt.append("__device__ __forceinline__ void sgpr_loop_asm_b%d(const float4* first, const float4* last, %s) {" % (B, sig))
+    if ts:
+        txt.append("// slice_bit = the clock bit (s_memrealtime, 10 ns units) that says whose turn it is; slot_bit = slice_bit when the wave's")
+        txt.append("// slot on its SIMD is odd, else 0.  The wave leaves the loop at whatever priority it had last.")
+        txt.append("__device__ __forceinline__ void sgpr_loop_asm_b%d_ts(const float4* first, const float4* last, unsigned slice_bit, unsigned slot_bit, %s) {" % (B, sig))
+    else:
+        txt.append("template <> constexpr int kSgprAsmTrip<%d> = %d;" % (B, trip // 16))
+        txt.append("__device__ __forceinline__ void sgpr_loop_asm_b%d(const float4* first, const float4* last, %s) {" % (B, sig))
     txt.append("  const char* q = reinterpret_cast<const char*>(first) - %d;     // biased: all immediate offsets positive" % trip)
     txt.append("  const char* qend = reinterpret_cast<const char*>(last) - %d;  // value of the pointer after the last trip's advance" % trip)
     txt.append("  asm volatile(")
     txt.append("\n".join(lines))
     txt.append("      : %s" % outs)
-    txt.append("      : %s" % ins)
+    txt.append("      : %s%s" % (ins, extra if ts else ""))
     txt.append("      : %s);" % ", ".join(clob))
     txt.append("}")
     return "\n".join(txt)
@@ -195,7 +228,7 @@ def main():
     parts = ["// nbx_sgpr_loop.inc -- GENERATED by tools/gen_sgpr_loop.py (see its docstring for the why); do not edit.",
              "// Included by nbx_kernels.hpp inside namespace nbx.  tests/test_isa_audit.py checks it is in sync with the generator.",
              "template <int B> constexpr int kSgprAsmTrip = 0;",
-             emit(2, 8), emit(4, 4), ""]
+             emit(2, 8), emit(4, 4), emit(2, 8, ts=True), emit(4, 4, ts=True), ""]
     open(out, "w").write("\n".join(parts))
 
 

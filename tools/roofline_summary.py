@@ -105,7 +105,7 @@ def main():
         wgx = -(-own // ((64 if ws else 256) * B))
         S = max(1, int(meta.get("Grid_Size", 0)) // (256 * wgx)) if meta.get("Grid_Size") else None
         shape = {"bodies_per_lane": B, "epilogue": {0: "slab", 1: "row"}.get(epi), "j_split": S, "wave_split": ws,
-                 "loop": {None: "cxx", "0": "cxx", "1": "asm"}.get(m.group(8), m.group(8))}
+                 "loop": {None: "cxx", "0": "cxx", "1": "asm", "2": "asm_ts"}.get(m.group(8), m.group(8))}
         alg_bytes = float(rec) * n + (3.0 * rec * own if epi == 1 else float(rec) * own * (S or 1))
     read_x1 = None if fetch_kib is None else fetch_kib * 1024.0
     traffic_x1 = None if (read_x1 is None or write_bytes is None) else read_x1 + write_bytes
