@@ -137,18 +137,19 @@ ForceLauncher<T> pick_force(const nbx_ctx* c, int epi) {
 // ceil(own / (256 B)) workgroups are spread over the CUs, and a launch takes as long as the fullest CU, which holds
 // r = ceil(workgroups / CUs) of them.  Measured on MI355X at n = 1048576 with the hand-scheduled loop for B = 2 and 4
 // (profiles/r02_reference_order_thresholds.txt), ms for r = 1, 2, 3, ...: B = 1: 31.0, 48.6, 70.3, 91, 112 (plain VALU ops);
-// B = 2: 31.5, 59.6, 88.5, 118;  B = 4: 59.3, 117.4, 175.6, 234.6 -- linear in r after the first workgroup.  Pick the B with the smallest
-// estimate; ties go to the larger B (fewer workgroups stream the j records).  Only the ratios matter, so the table
-// serves every n.
+// B = 2: 31.5, 59.6, 88.5, 118;  B = 4: 59.3, 117.4, 175.6, 234.6 -- linear in r after the first workgroup.  With two workgroups on
+// the fullest CU the time-sliced loop applies (LOOP_ASM_TS): B = 2, r = 2 then costs 58.0 (profiles/r02_time_sliced_ab.txt: 57.98 ms for
+// 262144 of 1M bodies), B = 4, r = 2 117.0.  Pick the B with the smallest estimate; ties go to the larger B (fewer workgroups stream
+// the j records).  Only the ratios matter, so the table serves every n.
 int reference_order_bodies_per_lane(int own, int cus, int max_b) {
-  static const struct { int b; double first, next; } kCost[] = {{1, 31.0, 20.2}, {2, 31.5, 28.8}, {4, 59.8, 58.2}};
+  static const struct { int b; double first, next, two; } kCost[] = {{1, 31.0, 20.2, 0.0}, {2, 31.5, 28.8, 58.0}, {4, 59.8, 58.2, 117.0}};
   int best = 1;
   double best_t = 0.0;
   for (const auto& k : kCost) {
     if (k.b > max_b) continue;
     const int wgs = ceil_div(own, kBlock * k.b);
     const int r = std::max(1, ceil_div(wgs, std::max(1, cus)));
-    const double t = k.first + k.next * (r - 1);
+    const double t = (r == 2 && k.two > 0.0) ? k.two : k.first + k.next * (r - 1);
     if (best_t == 0.0 || t <= best_t * 1.01) { best = k.b; best_t = std::min(t, best_t == 0.0 ? t : best_t); }
   }
   // Where two bodies per lane load every CU evenly too (twice the workgroups, all CUs with the same count), they win over four
