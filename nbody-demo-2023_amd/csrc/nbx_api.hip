@@ -153,7 +153,7 @@ int reference_order_bodies_per_lane(int own, int cus, int max_b) {
     if (best_t == 0.0 || t <= best_t * 1.01) { best = k.b; best_t = std::min(t, best_t == 0.0 ? t : best_t); }
   }
   // Where two bodies per lane load every CU evenly too (twice the workgroups, all CUs with the same count), they win over four
-  // by 2.5 % at 262144 owned bodies and tie from 524288 up (two waves per SIMD hide each other's scalar instructions;
+  // by 2.5 % at 262144 owned bodies and tie from 524288 up (the younger wave of a SIMD fills the older one's issue bubbles;
   // profiles/r02_loop_ab_asm_vs_cxx.txt, same process on two boxes): take them.
   if (best == 4 && max_b >= 2 && ceil_div(own, kBlock * 2) % std::max(1, cus) == 0) best = 2;
   return best;
