@@ -1381,3 +1381,44 @@ def test_cli_one_process_per_gpu_mode_with_a_world_of_one(tmp_path):
     assert [r[2] for r in _rows(lines)] == ["0.1432", "2.4341", "8.1256"]
     assert any("one process per rank" in ln and "RCCL" in ln for ln in lines)
     assert json.load(open(out))["exchange"] == "none"  # a single rank: nothing to exchange with
+
+
+# ---- bench.py's N > 1 path, rehearsed on the one GPU: same launcher line as the driver's ----------------------------------
+def _bench_under_torchrun(nproc, extra_env, args, port):
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + args
+    p = subprocess.run(cmd, env=dict(os.environ, **extra_env), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines  # the contract: ONE JSON line on stdout, whatever the native libraries print
+    return json.loads(lines[0])
+
+
+def test_bench_n_gt_1_path_with_two_ranks_sharing_the_gpu(nbx):
+    """Two ranks under torch.distributed.run, gloo for the exchange because RCCL refuses two ranks on one device: partition,
+    per-step all-gather, max-over-ranks timing and the energy all-reduce of bench.py's multi-GPU branch, checked against a
+    single context stepping the same system (same summation order for every rank count: bit-equal kenergy)."""
+    n, steps, warmup = 16384, 4, 2
+    line = _bench_under_torchrun(2, {"NBX_BENCH_BACKEND": "gloo"}, ["--bodies", str(n), "--steps", str(steps), "--warmup", str(warmup),
+                                                                     "--cpu-baseline", "none"], 29531)
+    assert line["n_gpus"] == 2 and line["steps"] == steps and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["n_bodies"] == n and line["config"]["bodies_per_gpu"] == n // 2
+    with nbx.Context(n, 32) as c:
+        c.upload(nbx.initial_conditions(n))
+        ke = c.step(steps + warmup)
+    assert rel_err(line["kenergy_after_run"], ke) < 1e-6, (line["kenergy_after_run"], ke)
+
+
+def test_bench_n_gt_1_path_over_rccl_with_a_world_of_one(nbx):
+    """The same branch over the real backend ("nccl" = RCCL), which a 1-GPU box can only run with one rank:
+    init_process_group(device_id), in-place all_gather_into_tensor on the device buffer, all_reduce of the timing and energy."""
+    n, steps, warmup = 16384, 4, 2
+    line = _bench_under_torchrun(1, {"NBX_BENCH_FORCE_DIST": "1"}, ["--bodies", str(n), "--steps", str(steps), "--warmup", str(warmup),
+                                                                     "--cpu-baseline", "none"], 29533)
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    with nbx.Context(n, 32) as c:
+        c.upload(nbx.initial_conditions(n))
+        ke = c.step(steps + warmup)
+    assert rel_err(line["kenergy_after_run"], ke) < 1e-6, (line["kenergy_after_run"], ke)
