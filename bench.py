@@ -217,7 +217,7 @@ def main():
     # N == 1 only: the multi-GPU runs use configs[3]'s n = 1048576; time a few steps of it on this one GPU as
     # well, so that scaling can also be read at equal n (pair/s is nearly flat in n here, see profiles/r01_sweep_*)
     same_n = None
-    rank8 = None
+    rank8 = rank4 = rank2 = None
     other_order = None
     if world == 1 and a.order == "auto" and not a.j_split and a.kernel in ("auto",):
         # the same workload with the OTHER summation order (see DESIGN.md "Summation order"): reference order is what
@@ -249,28 +249,33 @@ def main():
         t_big = (time.perf_counter() - tb) / 3.0
         same_n = {"n_bodies": 1048576, "steps": 3, "value": 1048576.0 ** 2 / t_big, "unit": "pair/s", "ms_per_step": 1e3 * t_big}
         big.close()
-        # what ONE rank of the 8-GPU configuration (configs[3]) computes per step: 131072 owned bodies against all 1048576
-        # resident records, on this GPU.  8-GPU speed-up over one GPU at the same n, before communication and skew, is the
-        # ratio of the two step times (the all-gather is 2 MiB sent / 14 MiB received per rank and step).
-        with nbx.Context(1048576, 32, i_begin=0, i_count=131072, n_alloc=1048576, **opts) as c8:
-            c8.upload(nbx.initial_conditions(1048576, 32))
-            for _ in range(2):
-                c8.step_local(); c8.commit()
-            c8.sync()
-            c8.profile(True)
-            tb = time.perf_counter()
-            for _ in range(6):
-                c8.step_local(); c8.commit()
-            c8.sync()
-            t_rank = (time.perf_counter() - tb) / 6.0
-            st8 = c8.stats()
-        rank8 = {"n_bodies": 1048576, "bodies_owned": 131072, "steps": 6, "ms_per_step": 1e3 * t_rank,
-                 "force_kernel_ms": st8["force_ms_total"] / max(1, st8["force_launches_timed"]),
-                 "roofline_frac": FLOP_PER_PAIR * 131072.0 * 1048576.0 / t_rank / (PEAK_FP32_VECTOR_TFLOPS * 1e12),
-                 "bodies_per_lane": st8["bodies_per_lane"], "grid": [st8["force_grid_x"], st8["force_grid_y"]],
-                 "inner_loop": {1: "cxx", 2: "asm", 3: "asm_ts"}.get(st8["inner_loop"], "?"),
-                 "implied_8gpu_speedup_before_communication": t_big / t_rank,
-                 "note": "measured on ONE GPU with a 131072-body slice; not an 8-GPU measurement"}
+        # what ONE rank of the 8-, 4- and 2-GPU forms of configs[3] computes per step: 131072 / 262144 / 524288 owned bodies against
+        # all 1048576 resident records, on this GPU.  The P-GPU speed-up over one GPU at the same n, before communication and skew,
+        # is the ratio of the two step times (at P = 8 the all-gather is 2 MiB sent / 14 MiB received per rank and step).
+        ic_big = nbx.initial_conditions(1048576, 32)
+        ranks = []
+        for P, reps in ((8, 6), (4, 4), (2, 3)):
+            own = 1048576 // P
+            with nbx.Context(1048576, 32, i_begin=0, i_count=own, n_alloc=1048576, **opts) as cP:
+                cP.upload(ic_big)
+                for _ in range(2):
+                    cP.step_local(); cP.commit()
+                cP.sync()
+                cP.profile(True)
+                tb = time.perf_counter()
+                for _ in range(reps):
+                    cP.step_local(); cP.commit()
+                cP.sync()
+                t_rank = (time.perf_counter() - tb) / reps
+                stP = cP.stats()
+            ranks.append({"n_bodies": 1048576, "bodies_owned": own, "steps": reps, "ms_per_step": 1e3 * t_rank,
+                          "force_kernel_ms": stP["force_ms_total"] / max(1, stP["force_launches_timed"]),
+                          "roofline_frac": FLOP_PER_PAIR * float(own) * 1048576.0 / t_rank / (PEAK_FP32_VECTOR_TFLOPS * 1e12),
+                          "bodies_per_lane": stP["bodies_per_lane"], "grid": [stP["force_grid_x"], stP["force_grid_y"]],
+                          "inner_loop": {1: "cxx", 2: "asm", 3: "asm_ts"}.get(stP["inner_loop"], "?"),
+                          "implied_%dgpu_speedup_before_communication" % P: t_big / t_rank,
+                          "note": "measured on ONE GPU with a %d-body slice; not a %d-GPU measurement" % (own, P)})
+        rank8, rank4, rank2 = ranks
 
     if rank == 0:
         pairs_per_step = float(n) * float(n)
@@ -338,6 +343,8 @@ def main():
             line["one_gpu_at_multi_gpu_n"] = same_n
         if rank8:
             line["one_rank_of_8_at_1m"] = rank8
+            line["one_rank_of_4_at_1m"] = rank4
+            line["one_rank_of_2_at_1m"] = rank2
         if other_order:
             line["other_summation_order"] = other_order
         if cpu:
