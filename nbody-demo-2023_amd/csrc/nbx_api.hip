@@ -327,6 +327,9 @@ int enqueue_force(nbx_ctx* c, int epi, double dt) {
   return NBX_OK;
 }
 
+// energy partials one step of this context's shape writes: one per workgroup of the kernel that integrates
+int step_ke_parts(const nbx_ctx* c) { return c->epi != EPI_SLAB ? (int)c->grid.x : ceil_div(c->i_count, kBlock); }
+
 // one local step: force (+ integrate) into the next buffer; does not swap
 template <typename T>
 int enqueue_step(nbx_ctx* c, double dt) {
@@ -334,9 +337,9 @@ int enqueue_step(nbx_ctx* c, double dt) {
   int rc = enqueue_force<T>(c, c->epi, dt);
   if (rc) return rc;
   if (c->epi != EPI_SLAB) {
-    c->ke_parts = c->grid.x;
+    c->ke_parts = step_ke_parts(c);
   } else {
-    const int blocks = ceil_div(c->i_count, kBlock);
+    const int blocks = step_ke_parts(c);
     hipLaunchKernelGGL((integrate_kernel<T>), dim3(blocks), dim3(kBlock), 0, c->stream,
                        (const T4*)c->posm[c->cur], (T4*)c->posm[c->cur ^ 1], (T4*)c->velm,
                        (const T4*)c->accp, c->S, c->own_pad, c->i_begin, c->i_count, (T)dt, c->ke_part);
@@ -675,6 +678,9 @@ static int step_common(nbx_ctx* c, double dt, int32_t nsteps, double* ke_last, d
       first += unit;
       c->steps_done += unit;
       c->graph_replays += 1;
+      // a replay enqueues through the captured nodes, not through enqueue_step: say here how many energy partials its
+      // last step leaves behind (nbx_upload zeroes the count; a cached graph must not leave it at zero)
+      c->ke_parts = step_ke_parts(c);
     }
     if (first == nsteps && ke_last) {  // the partials of the last captured step are in ke_part
       rc = enqueue_ke_reduce(c, 0);

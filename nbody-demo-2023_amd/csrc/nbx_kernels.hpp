@@ -542,7 +542,7 @@ __global__ __launch_bounds__(kBlock, 1) void force_jlane_kernel(const ForceArgs<
   // applied, so a request has D x NB/2 x 56 cycles of arithmetic to land under (one wave per SIMD has no other wave to
   // hide an L2 round trip behind).  Requests may run up to D blocks past the end of the array (zero-filled spare records,
   // kSgprOverread); what they return is never applied.
-  static_assert(D <= 8, "the spare records behind the array cover a prefetch of 8 blocks");
+  static_assert(64 * D <= kSgprOverread - 16, "the farthest request is D blocks of 64 records past the array (main loop: ra at k + 2 D <= K; the tail requests rb only when part of it is applied)");
   const float4* pj = a.posm + lane;
   const int K = a.n_alloc >> 6;  // records per lane; n_alloc is a multiple of 256, so K >= 4
   float4 ra[D], rb[D];
@@ -599,7 +599,9 @@ __global__ __launch_bounds__(kBlock, 1) void force_jlane_kernel(const ForceArgs<
     }
   }
   if (k < K) {  // fewer than 2 D records left: ra holds records k .. k + D - 1
-    request(rb, k + D);
+    // rb is requested only if any of it will be applied: the farthest request of the whole kernel is then the main loop's
+    // ra at k + 2 D <= K, i.e. at most D blocks (64 D records) past the array -- what kSgprOverread reserves
+    if (K - k > D) request(rb, k + D);
     apply_some(ra, K - k < D ? K - k : D);
     apply_some(rb, K - k - D > 0 ? K - k - D : 0);
   }
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(kBlock, 1) void force_jlane_kernel(const ForceArgs<
 // of 32 bytes.  NB <= 8: eight bodies are 48 SGPRs of coordinates.
 template <int NB, int D>
 __global__ __launch_bounds__(kBlock, 1) void force_jlane_kernel_f64(const ForceArgs<double> a, const int acc_only) {
-  static_assert(NB >= 1 && NB <= 8 && D >= 1 && D <= 8, "body state must fit the SGPR file; prefetch within the spare records");
+  static_assert(NB >= 1 && NB <= 8 && D >= 1 && 64 * D <= kSgprOverread - 16, "body state must fit the SGPR file; the farthest request is D blocks past the array");
   __shared__ double4 red[4][NB][65];  // [wave][body][lane] + one column of padding (2080 B between the lanes that read)
   __shared__ double ksum[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -678,7 +680,7 @@ __global__ __launch_bounds__(kBlock, 1) void force_jlane_kernel_f64(const ForceA
     for (int d = 0; d < D; ++d) apply_record(rb[d]);
   }
   if (k < K) {
-    request(rb, k + D);
+    if (K - k > D) request(rb, k + D);  // as in the fp32 kernel: never more than D blocks past the array
 #pragma unroll
     for (int d = 0; d < D; ++d)
       if (k + d < K) apply_record(ra[d]);

@@ -82,27 +82,38 @@ GSimulation::~GSimulation() {
   std::free(npp_global);
 }
 
-// Who am I?  NBODY_WORLD / NBODY_RANK, or the variables torchrun exports (WORLD_SIZE / RANK / LOCAL_RANK / MASTER_ADDR /
-// MASTER_PORT), so `python -m torch.distributed.run --no-python --nproc-per-node 8 ./nbody.x 1048576 100` works as well as a
-// shell loop.  Absent: one process, rank 0 of 1.
+// Who am I?  NBODY_WORLD / NBODY_RANK.  The variables torchrun exports (WORLD_SIZE / RANK / LOCAL_RANK / MASTER_ADDR /
+// MASTER_PORT) are honoured only with NBODY_USE_TORCHRUN_ENV=1 in the environment --
+//   NBODY_USE_TORCHRUN_ENV=1 python -m torch.distributed.run --no-python --nproc-per-node 8 ./nbody.x 1048576 100
+// -- because they are generic: a lone nbody.x started by a torchrun worker (or inside a PyTorchJob pod) inherits them
+// and must not wait two minutes for peers that were never launched.  Absent: one process, rank 0 of 1.  Nothing exits
+// here (this runs in the constructor): a bad description is remembered and reported by init_mpi() / start().
 void GSimulation::read_world_env() {
   const char* w = std::getenv("NBODY_WORLD");
   const char* r = std::getenv("NBODY_RANK");
-  if (!w) { w = std::getenv("WORLD_SIZE"); r = std::getenv("RANK"); }
+  const bool torchrun = env_int("NBODY_USE_TORCHRUN_ENV", 0) != 0;
+  if (!w && torchrun) { w = std::getenv("WORLD_SIZE"); r = std::getenv("RANK"); }
   world_size = (w && *w) ? std::atoi(w) : 1;
   world_rank = (r && *r) ? std::atoi(r) : 0;
   _multiprocess = w && *w;  // NBODY_WORLD=1 still takes the rank-group path (one-rank rehearsal of RCCL)
+  _world_error.clear();
   if (world_size < 1 || world_rank < 0 || world_rank >= world_size) {
-    std::cerr << "nbody.x: bad world description (world " << world_size << ", rank " << world_rank << ")" << std::endl;
-    std::exit(1);
+    _world_error = "bad world description (world " + std::to_string(world_size) + ", rank " + std::to_string(world_rank) + ")";
+    world_size = 1; world_rank = 0; _multiprocess = false;  // so that the banner still has one author
   }
   const char* a = std::getenv("NBODY_MASTER_ADDR");
-  if (!a) a = std::getenv("MASTER_ADDR");
+  if (!a && torchrun) a = std::getenv("MASTER_ADDR");
   if (a && *a) _master_addr = a;
   const char* p = std::getenv("NBODY_MASTER_PORT");
-  if (!p) p = std::getenv("MASTER_PORT");
+  if (!p && torchrun) p = std::getenv("MASTER_PORT");
   if (p && *p) _master_port = std::atoi(p);
-  _local_rank = env_int("LOCAL_RANK", -1);
+  _local_rank = env_int("NBODY_LOCAL_RANK", (torchrun || _multiprocess) ? env_int("LOCAL_RANK", -1) : -1);
+}
+
+void GSimulation::require_world() const {
+  if (_world_error.empty()) return;
+  std::cerr << "nbody.x: " << _world_error << std::endl;
+  std::exit(1);
 }
 
 // ver5_all/GSimulation.cpp:93-115.  The reference calls MPI_Init here and gives every rank n / size bodies (rank 0 the
@@ -110,6 +121,7 @@ void GSimulation::read_world_env() {
 // of nbx_partition -- what each rank's GPU will own.  No network is touched before start().
 void GSimulation::init_mpi() {
   read_world_env();
+  require_world();
   std::free(npp_global);
   npp_global = static_cast<int*>(std::malloc(sizeof(int) * (size_t)world_size));
   npp = 0;
@@ -188,6 +200,7 @@ void GSimulation::start() {
   const int nsteps = get_nsteps();
   const int sfreq = get_sfreq();
   const double dt = (double)get_tstep();
+  require_world();
 
   // ver5_all device word (ver5_all/main.cpp:40-47): 1 = "cpu", 2 = "gpu", 3 = "cpu+gpu", 0 = not given.  libnbx has no
   // CPU engine by design (no fallback may stand in for the HIP path), so "cpu" is refused here -- also when the

@@ -42,7 +42,8 @@ class GSimulation {
   int get_devices() { return _devices; }
 
   // ver5_all/GSimulation.hpp:60-65 -- the MPI surface.  One process: rank 0 of 1 owning all bodies.  Several
-  // processes (one per GPU; NBODY_WORLD / NBODY_RANK or torchrun's WORLD_SIZE / RANK in the environment): the
+  // processes (one per GPU; NBODY_WORLD / NBODY_RANK in the environment, or torchrun's WORLD_SIZE / RANK when
+  // NBODY_USE_TORCHRUN_ENV=1 opts in): the
   // i-block partition of nbx_partition (include/nbx.h); see init_mpi() in GSimulation.cpp.  Only rank 0 prints.
   int world_rank;
   int world_size;
@@ -77,7 +78,9 @@ class GSimulation {
   bool _multiprocess;
   std::string _master_addr;
   int _master_port, _local_rank;
+  std::string _world_error;  // a bad NBODY_WORLD / NBODY_RANK, reported by init_mpi() / start() (never by the constructor)
   void read_world_env();
+  void require_world() const;
 
   void allocate_store(int n);
   void release_store();

@@ -5,8 +5,10 @@
 // token (ncclUniqueId -> nbx_comm_unique_id / nbx_group_create_rank, include/nbx.h).  One TCP round does it:
 //   every rank r > 0 connects to rank 0 (retrying while rank 0 is still starting), sends a fixed-size hello
 //   {magic, rank, world, job signature}, and receives {status, token};
-//   rank 0 accepts world-1 connections, checks each hello (same world, distinct ranks in range, same job signature:
-//   n, steps, precision -- a mis-launched rank is refused instead of deadlocking the first collective), answers, closes.
+//   rank 0 accepts connections until world-1 well-formed hellos are in (anything else on the port is dropped), checks
+//   them all (same world, distinct ranks in range, same job signature: n, steps, precision) and only THEN answers --
+//   every rank gets the same verdict, so a mis-launched or missing rank refuses the whole job at once instead of
+//   leaving the ranks that were already accepted inside ncclCommInitRank.
 // No data path runs over these sockets.  Environment (GSimulation::init_mpi): NBODY_WORLD / NBODY_RANK or torchrun's
 // WORLD_SIZE / RANK, NBODY_MASTER_ADDR / NBODY_MASTER_PORT or MASTER_ADDR / MASTER_PORT (default 127.0.0.1:29417).
 #ifndef NBX_HOST_RENDEZVOUS_HPP
@@ -88,32 +90,48 @@ inline bool exchange(int rank, int world, const std::string& addr, int port, con
       ::close(ls);
       return false;
     }
+    // Two phases.  (1) Collect a hello from every other rank -- nobody is answered yet.  A connection that does not open
+    // with the magic word (a port scanner, a health check, a stray client) is dropped and does not count.  (2) One verdict
+    // for the whole job goes to every rank that said hello: a rank is never told "go" -- and left to wait inside
+    // ncclCommInitRank for a communicator that cannot form -- when a later hello turns out to be wrong or missing.
     std::vector<char> seen((size_t)world, 0);
     seen[0] = 1;
+    std::vector<int> fds;  // every connection that said a well-formed hello, good or bad: all get the verdict
     bool ok = true;
-    for (int k = 1; k < world && ok; ++k) {
+    int have = 1;
+    while (have < world) {
       const long left = (long)std::chrono::duration_cast<std::chrono::seconds>(deadline - clock::now()).count();
-      if (left <= 0) { *err = "rank 0 timed out waiting for " + std::to_string(world - k) + " rank(s)"; ok = false; break; }
+      if (left <= 0) { *err = "rank 0 timed out waiting for " + std::to_string(world - have) + " rank(s)"; ok = false; break; }
       timeval tv; tv.tv_sec = left; tv.tv_usec = 0;
       ::setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);  // bounds accept()
       const int fd = ::accept(ls, NULL, NULL);
-      if (fd < 0) { *err = "rank 0 timed out waiting for " + std::to_string(world - k) + " rank(s)"; ok = false; break; }
-      set_timeouts(fd, 10);
-      Hello h;
-      Reply r; std::memset(&r, 0, sizeof r);
-      if (!recv_all(fd, &h, sizeof h)) { *err = "short hello from a rank"; ok = false; }
-      else if (h.magic != kMagic || h.world != world || h.rank <= 0 || h.rank >= world || seen[(size_t)h.rank] ||
-               std::memcmp(h.sig, sig, sizeof h.sig) != 0) {
-        *err = "rank " + std::to_string(h.rank) + " of " + std::to_string(h.world) + " does not belong to this job (n/steps/precision " +
-               std::to_string(h.sig[0]) + "/" + std::to_string(h.sig[1]) + "/" + std::to_string(h.sig[2]) + ", or a duplicate rank)";
-        ok = false;
+      if (fd < 0) {
+        if (errno == EINTR) continue;
+        *err = "rank 0 timed out waiting for " + std::to_string(world - have) + " rank(s)"; ok = false; break;
       }
-      r.status = ok ? (root_ok ? 0 : 2) : 1;
-      if (ok) { std::memcpy(r.token, token, kTokenBytes); seen[(size_t)h.rank] = 1; }
-      if (!send_all(fd, &r, sizeof r) && ok) { *err = "cannot answer rank " + std::to_string(h.rank); ok = false; }
-      ::close(fd);
+      set_timeouts(fd, (int)(left < 10 ? left : 10));
+      Hello h;
+      if (!recv_all(fd, &h, sizeof h) || h.magic != kMagic) { ::close(fd); continue; }  // not one of ours: ignore it
+      fds.push_back(fd);
+      if (h.world != world || h.rank <= 0 || h.rank >= world || seen[(size_t)h.rank] || std::memcmp(h.sig, sig, sizeof h.sig) != 0) {
+        if (ok)
+          *err = "rank " + std::to_string(h.rank) + " of " + std::to_string(h.world) + " does not belong to this job (n/steps/precision " +
+                 std::to_string(h.sig[0]) + "/" + std::to_string(h.sig[1]) + "/" + std::to_string(h.sig[2]) + ", or a duplicate rank)";
+        ok = false;
+        have += 1;  // it took a seat: the job is refused as a whole once everybody has been heard (or the deadline passes)
+        continue;
+      }
+      seen[(size_t)h.rank] = 1;
+      have += 1;
     }
     ::close(ls);
+    Reply r; std::memset(&r, 0, sizeof r);
+    r.status = ok ? (root_ok ? 0 : 2) : 1;
+    if (ok && root_ok) std::memcpy(r.token, token, kTokenBytes);
+    for (size_t k = 0; k < fds.size(); ++k) {
+      if (!send_all(fds[k], &r, sizeof r) && ok) { *err = "cannot answer a rank"; ok = false; }  // that rank times out by itself
+      ::close(fds[k]);
+    }
     if (ok && !root_ok) { *err = "rank 0 could not initialise; the other ranks were told to stop"; return false; }
     return ok;
   }
@@ -142,7 +160,7 @@ inline bool exchange(int rank, int world, const std::string& addr, int port, con
   ::close(fd);
   if (!ok) { *err = "rank " + std::to_string(rank) + ": rendezvous with rank 0 broke off"; return false; }
   if (r.status == 2) { *err = "rank 0 could not initialise (see its message); stopping"; return false; }
-  if (r.status != 0) { *err = "rank " + std::to_string(rank) + " was refused by rank 0 (different world size, n, steps or precision)"; return false; }
+  if (r.status != 0) { *err = "rank " + std::to_string(rank) + ": job refused by rank 0 (some rank has a different world size, n, steps or precision, is a duplicate, or never came)"; return false; }
   std::memcpy(token, r.token, kTokenBytes);
   return true;
 }

@@ -361,6 +361,27 @@ def test_upload_download_roundtrip_and_state_errors(nbx):
         assert e.value.code == nbx.NBX_ERR_STATE
 
 
+@pytest.mark.parametrize("n,kernel", [(777, 0), (2304, 0), (16384, 0), (16384, 1)])
+def test_reupload_then_cached_graph_replay_still_reports_the_energy(nbx, n, kernel):
+    """upload; step(10); upload; step(10) with graph replay on.  The second step(10) enqueues nothing through
+    enqueue_step (the window's graph is cached), so the count of energy partials has to come from the replay itself --
+    it used to stay at the zero nbx_upload leaves and the energy came back as 0.0."""
+    ic = nbx.initial_conditions(n)
+    with nbx.Context(n, use_graph=1, kernel_variant=kernel) as c:
+        c.upload(ic)
+        ke1 = c.step(10)
+        assert c.stats()["graph_replays"] == 1 and ke1 > 0.0
+        c.upload(ic)
+        assert c.step(0) == 0.0
+        ke2 = c.step(10)
+        assert c.stats()["graph_replays"] == 2
+        assert ke2 == ke1
+        assert c.step(0) == ke1 and 0.5 * c.kenergy_partial() == ke1
+    with nbx.Context(n, use_graph=2, kernel_variant=kernel) as c:  # plain launches: the same number
+        c.upload(ic)
+        assert c.step(10) == ke1
+
+
 def test_stats_and_profile(nbx):
     n = 8192
     with nbx.Context(n) as c:

@@ -64,6 +64,38 @@ def test_rank_with_another_problem_size_is_refused(driver):
     assert res[1][0] == 1 and "refused by rank 0" in res[1][1]
 
 
+def test_one_verdict_for_the_whole_job(driver):
+    """rank 1 is fine and says hello FIRST, rank 2 belongs to another job.  Rank 0 answers nobody before it
+    has heard everybody, so rank 1 is refused as well -- it must not be sent into ncclCommInitRank with a token for a
+    communicator that can never form."""
+    port = _free_port()
+    p0 = subprocess.Popen([driver, "0", "3", str(port), "1000", "20"], stdout=subprocess.PIPE, text=True)
+    time.sleep(0.3)
+    p1 = subprocess.Popen([driver, "1", "3", str(port), "1000", "20"], stdout=subprocess.PIPE, text=True)
+    time.sleep(1.0)
+    assert p1.poll() is None  # still waiting for the verdict: nothing was answered early
+    t0 = time.time()
+    p2 = subprocess.Popen([driver, "2", "3", str(port), "2000", "20"], stdout=subprocess.PIPE, text=True)
+    res = [(p.wait(timeout=60), p.stdout.read().strip()) for p in (p0, p1, p2)]
+    assert time.time() - t0 < 10
+    assert res[0][0] == 1 and "does not belong to this job" in res[0][1]
+    assert all(rc == 1 and "refused by rank 0" in out for rc, out in res[1:]), res
+
+
+def test_a_stray_connection_on_the_port_does_not_end_the_job(driver):
+    """A client that is not a rank (no magic word, or a short write) is dropped; the rendezvous completes."""
+    port = _free_port()
+    p0 = subprocess.Popen([driver, "0", "2", str(port), "1000", "20"], stdout=subprocess.PIPE, text=True)
+    time.sleep(0.5)
+    for junk in (b"GET / HTTP/1.0\r\n\r\n" + b"x" * 64, b"\x00\x01"):
+        s = socket.create_connection(("127.0.0.1", port), timeout=5)
+        s.sendall(junk)
+        s.close()
+    p1 = subprocess.Popen([driver, "1", "2", str(port), "1000", "20"], stdout=subprocess.PIPE, text=True)
+    res = [(p.wait(timeout=60), p.stdout.read().strip()) for p in (p0, p1)]
+    assert all(rc == 0 and out.startswith("ok 030a11") for rc, out in res), res
+
+
 def test_missing_rank_times_out_instead_of_hanging(driver):
     port = _free_port()
     t0 = time.time()
@@ -84,6 +116,39 @@ def test_nbody_x_refuses_a_world_with_empty_ranks_on_every_rank():
         p = subprocess.run([exe, "300", "10"], env=dict(os.environ, NBODY_WORLD="3", NBODY_RANK=str(rank)), capture_output=True, text=True, timeout=60)
         assert p.returncode == 1 and "start at most that many ranks" in p.stderr
         assert ("Initialize Gravity Simulation" in p.stdout) == (rank == 0)  # only rank 0 prints
+
+
+def test_inherited_torchrun_variables_do_not_start_the_multi_process_mode():
+    """WORLD_SIZE / RANK are generic (any child of a torchrun worker inherits them).  Without the opt-in a lone
+    nbody.x is a one-process run: it prints its banner as rank 0 and fails for the one reason this container offers (no
+    HIP device) -- at once, not after waiting two minutes for seven peers.  With NBODY_USE_TORCHRUN_ENV=1 the same
+    variables are obeyed: rank 3 of 8 is silent and refuses 300 bodies for 8 ranks."""
+    exe = os.path.join(HOST, "nbody.x")
+    inherited = dict(os.environ, WORLD_SIZE="8", RANK="3", LOCAL_RANK="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    t0 = time.time()
+    p = subprocess.run([exe, "300", "10"], env=inherited, capture_output=True, text=True, timeout=60)
+    assert time.time() - t0 < 20
+    assert "Initialize Gravity Simulation" in p.stdout and "start at most that many ranks" not in p.stderr
+    if not os.path.exists("/dev/kfd"):
+        assert p.returncode == 1 and "no HIP device" in p.stderr
+    p = subprocess.run([exe, "300", "10"], env=dict(inherited, NBODY_USE_TORCHRUN_ENV="1"), capture_output=True, text=True, timeout=60)
+    assert p.returncode == 1 and p.stdout == "" and "start at most that many ranks" in p.stderr
+
+
+def test_bad_world_description_is_reported_by_start_not_by_the_constructor(tmp_path):
+    """The constructor never exits the process (an embedding program may build a GSimulation it never starts)."""
+    src = tmp_path / "ctor_probe.cpp"
+    src.write_text('#include "GSimulation.hpp"\n#include <cstring>\nint main(int argc, char** argv) { GSimulation sim; std::cout << "constructed" << std::endl;\n'
+                   '  if (argc > 1 && !std::strcmp(argv[1], "mpi")) sim.init_mpi();\n  if (argc > 1 && !std::strcmp(argv[1], "start")) sim.start();\n  return 0; }\n')
+    exe = str(tmp_path / "ctor_probe.x")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I", HOST, str(src), os.path.join(HOST, "GSimulation.cpp"), "-o", exe,
+                           "-L" + PKG, "-lnbx", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+    env = dict(os.environ, NBODY_WORLD="2", NBODY_RANK="5")
+    p = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and "constructed" in p.stdout
+    for how in ("mpi", "start"):
+        p = subprocess.run([exe, how], env=env, capture_output=True, text=True, timeout=60)
+        assert p.returncode == 1 and "constructed" in p.stdout and "bad world description (world 2, rank 5)" in p.stderr
 
 
 def test_init_mpi_shares_follow_the_native_partition(nbx, tmp_path):
