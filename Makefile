@@ -11,7 +11,7 @@ lib: $(PKG)/libnbx.so
 
 $(PKG)/nbx_api.o: $(CSRC)/nbx_api.hip $(CSRC)/nbx_internal.hpp $(CSRC)/nbx_kernels.hpp $(CSRC)/nbx_sgpr_loop.inc $(CSRC)/nbx_jlane_loop.inc include/nbx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(PKG)/nbx_group.o: $(CSRC)/nbx_group.hip $(CSRC)/nbx_internal.hpp include/nbx.h
+$(PKG)/nbx_group.o: $(CSRC)/nbx_group.hip $(CSRC)/nbx_internal.hpp $(CSRC)/nbx_watchdog.hpp include/nbx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(PKG)/nbx_ic.o: $(CSRC)/nbx_ic.cpp include/nbx.h
 	$(HIPCC) -O2 -std=c++17 -fPIC -Wall -ffp-contract=off -c $< -o $@

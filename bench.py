@@ -11,10 +11,17 @@ position blocks).  State is resident in HBM before the timed region starts.
 Workload: N == 1 -> BASELINE.json configs[2] (n = 262144, fp32: the roofline configuration the metric's
 target is quoted on); N > 1 -> configs[3] (n = 1048576 block-partitioned over the N ranks, one RCCL
 all-gather of the positions per step).  Prints ONE JSON line on rank 0.
+
+An N > 1 line validates itself (all outside the timed region): `parity` = the same sharded simulation restarted
+from the seed-42 state, 10 steps against the reference's own trace; `ranks` = force-kernel and all-gather times
+of every rank (min / mean / max, skew, bytes, devices); `native_rank_group` = the drop-in's own multi-process
+path (nbody.x per rank: TCP rendezvous, ncclCommInitRank, in-place ncclAllGather inside libnbx) run on the same
+GPUs and compared with the torch.distributed path.
 """
 import argparse
 import json
 import os
+import socket
 import statistics
 import subprocess
 import sys
@@ -101,26 +108,132 @@ def cpu_baseline(kind, n_gpu, precision, build="pinned"):
         what = "oracle C restatement of ver7 (gcc -O2 -fopenmp)"
     return {
         "value": float(n_cpu) ** 2 / t, "unit": "pair/s", "cores": threads, "kind": kind,
-        "sample": "%s, n=%d, %d steps (first discarded), median step %.3f s, fp%d, OMP_NUM_THREADS=%d"
-                  % (what, n_cpu, steps, t, precision, threads),
+        # `cores` = the threads the baseline really ran on (affinity mask capped by the cgroup quota); the box itself has more
+        "cores_on_box": os.cpu_count(),
+        "sample": "%s, n=%d, %d steps (first discarded), median step %.3f s, fp%d, OMP_NUM_THREADS=%d of %s logical CPUs on the box"
+                  % (what, n_cpu, steps, t, precision, threads, os.cpu_count()),
     }
+
+
+PARITY_FIXTURES = {(262144, 32): "ver7_f32_n262144_s7.json", (16384, 32): "ver7_f32_n16384_s500.json",
+                   (2000, 32): "ver7_f32_n2000_s500.json", (262144, 64): "ver7_f64_n262144_s3.json",
+                   (16384, 64): "ver7_f64_n16384_s60.json", (1048576, 32): "ver7_f32_n1048576_s10.json"}
+
+
+def parity_fixture(n, precision):
+    """The reference's per-step kenergy trace for this n, if tests/golden/ holds one (made by oracle/gen_golden.py from the
+    reference's unmodified ver7 source)."""
+    name = PARITY_FIXTURES.get((n, precision))
+    if not name:
+        return None, None
+    return name, json.load(open(os.path.join(ROOT, "tests", "golden", name)))
 
 
 def parity_probe(nbx, n, precision):
     """Cheap in-run check against the reference's golden trace when a fixture exists for this n."""
     import numpy as np
-    name = {(262144, 32): "ver7_f32_n262144_s7.json", (16384, 32): "ver7_f32_n16384_s500.json",
-            (2000, 32): "ver7_f32_n2000_s500.json", (262144, 64): "ver7_f64_n262144_s3.json",
-            (16384, 64): "ver7_f64_n16384_s60.json"}.get((n, precision))
+    name, g = parity_fixture(n, precision)
     if not name:
         return None
-    g = json.load(open(os.path.join(ROOT, "tests", "golden", name)))
     k = min(7, g["nsteps"])
     with nbx.Context(n, precision) as c:
         c.upload(nbx.initial_conditions(n, precision))
         ke = c.step_trace(k)
     ref = np.array(g["kenergy"][:k])
     return {"fixture": name, "steps": k, "max_rel_kenergy_err": float((abs(ke - ref) / ref).max())}
+
+
+def parity_probe_sharded(sim, ic, n, precision, rank):
+    """N > 1: the SAME sharded simulation the timed region used (same ranks, same collective), restarted from the seed-42
+    state and stepped 10 times with the energy all-reduced after every step -- compared on rank 0 with the reference's own
+    trace (n = 1048576: 10 steps of the unmodified ver7 binary, tests/golden/ver7_f32_n1048576_s10.json).  Collective: every
+    rank calls it.  Returns (record for the JSON line or None, the per-step energies)."""
+    name, g = parity_fixture(n, precision)
+    k = min(10, g["nsteps"]) if g else 10
+    sim.upload(ic)
+    ke = []
+    for _ in range(k):
+        sim.step(1)
+        ke.append(sim.kenergy())
+    if rank != 0 or not g:
+        return None, ke
+    ref = g["kenergy"][:k]
+    err = [abs(a - b) / abs(b) for a, b in zip(ke, ref)]
+    return {"fixture": name, "steps": k, "max_rel_kenergy_err": max(err), "rel_kenergy_err_per_step": err,
+            "gate": 1e-4, "pass": max(err) < 1e-4, "ranks": sim.world}, ke
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def native_rank_group_check(dist, rank, world, device, n, precision, ke_torch_path, window=10):
+    """The drop-in's OWN multi-process path on the same GPUs: one `nbody.x` child per rank (NBODY_WORLD / NBODY_RANK), i.e.
+    host/rendezvous.hpp (TCP hand-over of the RCCL token) -> nbx_group_create_rank (ncclCommInitRank) -> one in-place
+    ncclAllGather per step inside libnbx (csrc/nbx_group.hip) -> collective energy and download: the counterpart of the
+    reference's init_mpi / mpi_bcast_all / mpi_gather_acc (ver5_all/GSimulation.cpp:93-115,170-214).  bench.py's timed
+    region exchanges through torch.distributed; without this leg the native path would never run on more than one GPU.
+
+    A child per rank rather than an in-process group: whatever happens in there (an RCCL refusal, the collective watchdog
+    ending a stuck rank with status 75) ends the CHILD; this process goes on and prints its line.  Two windows of `window`
+    steps: the first carries RCCL's lazy channel set-up, the second is the timing.  Collective: every rank calls it."""
+    port = [_free_port() if rank == 0 else None]
+    dist.broadcast_object_list(port, src=0)
+    exe = os.path.join(PKG, "host", "nbody.x" if precision == 32 else "nbody_fp64.x")
+    res = {"rank": rank, "returncode": None}
+    with tempfile.TemporaryDirectory() as td:
+        jpath = os.path.join(td, "native.json")
+        env = dict(os.environ, NBODY_WORLD=str(world), NBODY_RANK=str(rank), NBODY_LOCAL_RANK=str(device), NBODY_MASTER_ADDR="127.0.0.1",
+                   NBODY_MASTER_PORT=str(port[0]), NBODY_SFREQ=str(window), NBODY_JSON=jpath, NBODY_COLLECTIVE_TIMEOUT="60",
+                   NBODY_RENDEZVOUS_TIMEOUT="60")
+        for k in ("NBODY_GPUS", "NBX_EXCHANGE", "NBODY_KERNEL", "NBODY_ORDER", "NBODY_JSPLIT", "NBODY_BPL"):
+            env.pop(k, None)
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run([exe, str(n), str(2 * window)], env=env, capture_output=True, text=True, timeout=420)
+            res["returncode"] = p.returncode
+            if p.returncode != 0:
+                res["stderr_tail"] = p.stderr[-400:]
+            if rank == 0 and p.returncode == 0:
+                res["json"] = json.load(open(jpath))
+        except Exception as e:  # a child that could not even be started or timed out: reported, never raised
+            res["error"] = "%s: %s" % (type(e).__name__, e)
+        res["wall_s"] = time.perf_counter() - t0
+    allres = [None] * world
+    dist.all_gather_object(allres, res)
+    if rank != 0:
+        return None
+    out = {"binary": os.path.relpath(exe, ROOT), "ranks": world, "steps": 2 * window, "returncodes": [r["returncode"] for r in allres],
+           "path": "host/rendezvous.hpp -> nbx_group_create_rank (ncclCommInitRank) -> in-place ncclAllGather per step (csrc/nbx_group.hip)"}
+    bad = [r for r in allres if r["returncode"] != 0]
+    if bad:
+        out["error"] = "; ".join("rank %d: %s" % (r["rank"], r.get("error") or r.get("stderr_tail") or "status %r" % r["returncode"]) for r in bad)
+        return out
+    j = allres[0]["json"]
+    w = j["windows"]
+    out.update({"exchange": j["exchange"], "uses_rccl": j["uses_rccl"], "one_process_per_rank": j["one_process_per_rank"],
+                "ms_per_step": 1e3 * w[1]["seconds"] / window, "ms_per_step_first_window": 1e3 * w[0]["seconds"] / window,
+                "pair_per_s": float(n) * n * window / w[1]["seconds"], "kenergy_step%d" % window: w[0]["kenergy"],
+                "wall_s_max_over_ranks": max(r["wall_s"] for r in allres)})
+    if ke_torch_path is not None:
+        # same partition, same kernels, the ranks' fp64 energy partials added in rank order (native) or by the all-reduce (torch)
+        d = abs(w[0]["kenergy"] - ke_torch_path) / abs(ke_torch_path)
+        out["rel_diff_vs_torch_path"] = d
+        out["kenergy_equal_to_torch_path"] = bool(d < 1e-12)
+    name, g = parity_fixture(n, precision)
+    if g and g["nsteps"] >= window:
+        out["rel_kenergy_err_vs_reference_step%d" % window] = abs(w[0]["kenergy"] - g["kenergy"][window - 1]) / g["kenergy"][window - 1]
+    return out
+
+
+def ran_shape(st):
+    """The launch shape in the vocabulary of profiles/roofline_traffic.json's `profiled_shape` (tools/roofline_summary.py)."""
+    return {"bodies_per_lane": st["bodies_per_lane"], "epilogue": "row" if st["fused_epilogue"] == 1 else "slab", "j_split": st["j_split"],
+            "wave_split": st["kernel_variant"] == 3, "loop": {1: "cxx", 2: "asm", 3: "asm_ts"}.get(st["inner_loop"], "?")}
 
 
 def main():
@@ -186,7 +299,7 @@ def main():
     opts = dict(bodies_per_lane=a.bodies_per_lane, j_split=a.j_split, summation_order={"auto": 0, "reference": 1, "tree": 2}[a.order],
                 kernel_variant={"auto": 0, "lds": 1, "sgpr": 2, "sgprw": 3, "jlane": 6}[a.kernel])
 
-    parity = parity_probe(nbx, n, a.precision) if (rank == 0 and world == 1) else None
+    parity = parity_probe(nbx, n, a.precision) if (rank == 0 and not use_dist) else None  # N > 1: parity_probe_sharded below
 
     ic = nbx.initial_conditions(n, a.precision)  # synthetic: the reference's seed-42 generator
     sim = sharded.ShardedSimulation(n, a.precision, dist=dist if use_dist else None, force_collective=force_dist, **opts)
@@ -202,17 +315,40 @@ def main():
     sim.step(a.warmup)
     fence()
     sim.engine.ctx.profile(True)  # HIP events around every force launch, on the context's own stream
+    if use_dist:
+        sim.profile_exchange(True)  # and around every all-gather (events on the same stream over RCCL)
     t0 = time.perf_counter()
     sim.step(a.steps)
     fence()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed = own_elapsed = t1 - t0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = sim.engine.ctx.stats()
     ke = sim.kenergy()
+
+    # N > 1: what every rank did, gathered to rank 0 -- a sub-6x result must be diagnosable from the line alone
+    breakdown = native = None
+    if use_dist:
+        xms = sim.exchange_ms()
+        sim.profile_exchange(False)
+        report = {"rank": rank, "device": torch.cuda.current_device(), "host": socket.gethostname(), "bodies_owned": st["i_count"],
+                  "force_ms_mean": st["force_ms_total"] / max(1, st["force_launches_timed"]), "allgather_ms": xms, "elapsed_s": own_elapsed}
+        reports = sharded.gather_rank_reports(dist, report)
+        if rank == 0:
+            breakdown = sharded.summarise_rank_reports(reports, sim.block * sim.rec)
+            breakdown["backend"] = dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (rehearsal: ranks share a GPU, exchange staged through the host)")
+            breakdown["world_seen"] = dist.get_world_size()
+            breakdown["allgather_share_of_step"] = breakdown["allgather_ms_per_step"]["mean"] / (1e3 * elapsed / a.steps)
+        # parity of THIS multi-rank form against the reference's own trace, and the native drop-in path on the same GPUs
+        parity, ke_trace = parity_probe_sharded(sim, ic, n, a.precision, rank)
+        if dist.get_backend() == "nccl" and not os.environ.get("NBX_BENCH_NO_NATIVE"):
+            native = native_rank_group_check(dist, rank, dist.get_world_size(), torch.cuda.current_device(), n, a.precision,
+                                             ke_trace[9] if len(ke_trace) >= 10 else None)
+        elif rank == 0:
+            native = {"skipped": "rehearsal backend %s: RCCL refuses several ranks on one device" % dist.get_backend()}
 
     # N == 1 only: the multi-GPU runs use configs[3]'s n = 1048576; time a few steps of it on this one GPU as
     # well, so that scaling can also be read at equal n (pair/s is nearly flat in n here, see profiles/r01_sweep_*)
@@ -290,18 +426,28 @@ def main():
         rec = 16 if a.precision == 32 else 32
         own = st["i_count"]
         alg_bytes = float(rec) * n + (3.0 * rec * own if st["fused_epilogue"] == 1 else float(rec) * own * st["j_split"])
+        # PMC counters cannot be collected inside this run; `traffic` is the committed result of scripts/profile.sh and is
+        # emitted ONLY when that profile was taken on the very launch shape that ran here (else null + the reason)
         traffic = traffic_x1 = None
         traffic_shape = None
+        traffic_note = "no profiles/roofline_traffic.json"
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("n") == n and tj.get("gpus", 1) == a.gpus and tj.get("precision", 32) == a.precision:
+                traffic_shape = tj.get("profiled_shape")
+                same_job = tj.get("n") == n and tj.get("gpus", 1) == a.gpus and tj.get("precision", 32) == a.precision
+                if same_job and traffic_shape == ran_shape(st):
                     traffic = tj.get("hbm_bytes_per_launch")
                     traffic_x1 = tj.get("hbm_bytes_per_launch_fetch_x1")
-                    traffic_shape = tj.get("profiled_shape")
-            except Exception:
+                    traffic_note = "PMC passes of %s on this shape" % tj.get("source", "scripts/profile.sh")
+                elif same_job:
+                    traffic_note = "the committed PMC profile was taken on another launch shape (%s); this run used %s" % (json.dumps(traffic_shape), json.dumps(ran_shape(st)))
+                else:
+                    traffic_note = "the committed PMC profile is for n=%s gpus=%s fp%s" % (tj.get("n"), tj.get("gpus", 1), tj.get("precision", 32))
+            except Exception as e:
                 traffic = None
+                traffic_note = "unreadable profiles/roofline_traffic.json: %s" % e
         line = {
             "metric": "pair-interactions/s", "value": value, "unit": "pair/s", "n_gpus": a.gpus,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
@@ -324,7 +470,8 @@ def main():
                          # PMC passes of scripts/profile.sh, per launch: `traffic` = 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950
                          # correction, calibrated for 16-B/lane vector loads: an upper bound for this kernel's scalar loads),
                          # `traffic_fetch_x1` = FETCH_SIZE + WRITE_SIZE as counted; both far below what 8 TB/s would move
-                         "traffic_fetch_x1": traffic_x1, "traffic_profiled_shape": traffic_shape,
+                         "traffic_fetch_x1": traffic_x1, "traffic_profiled_shape": traffic_shape, "traffic_shape_ran": ran_shape(st),
+                         "traffic_note": traffic_note,
                          "algorithmic_bytes": alg_bytes, "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
                          "algorithmic_GBps": alg_bytes / (launch_ms * 1e-3) * 1e-9 if launch_ms > 0 else None,
                          "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": st["pairs_per_launch"],
@@ -339,6 +486,10 @@ def main():
         }
         if parity:
             line["parity"] = parity
+        if breakdown:
+            line["ranks"] = breakdown
+        if native:
+            line["native_rank_group"] = native
         if same_n:
             line["one_gpu_at_multi_gpu_n"] = same_n
         if rank8:

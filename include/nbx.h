@@ -237,6 +237,21 @@ int nbx_group_create_rank(nbx_group** out, int32_t n, int32_t precision, int32_t
                           int32_t device, const nbx_opts* opts);
 
 /*
+ * Bound on every BLOCKING collective of a group.  The reference's MPI mode hangs for ever when a rank dies (init_mpi,
+ * mpi_bcast_all, mpi_gather_acc: ver5_all/GSimulation.cpp:93-115,170-214), and so does RCCL: a rank whose peer is gone sits
+ * in ncclCommInitRank or in the stream synchronisation behind an all-gather without error.  libnbx watches those calls
+ * -- ncclCommInitRank in nbx_group_create_rank, the synchronisation of nbx_group_step when kenergy_out != NULL,
+ * nbx_group_download, nbx_group_destroy -- from a host thread: when one of them has not returned `seconds` after it
+ * should have (the limit is `seconds` plus four times the measured duration of the steps still queued in front of it),
+ * the thread writes which call is stuck on which rank to stderr and ends the process with
+ * _exit(NBX_EXIT_COLLECTIVE_TIMEOUT): a collective cannot be abandoned from inside the process, so the bound is on the
+ * process; there is no re-exec and no retry.  Process-wide.  Default: the environment's NBX_COLLECTIVE_TIMEOUT, else 120;
+ * seconds <= 0 switches the watchdog off.  nbody.x sets it from NBODY_COLLECTIVE_TIMEOUT.
+ */
+#define NBX_EXIT_COLLECTIVE_TIMEOUT 75
+int nbx_collective_timeout(double seconds);
+
+/*
  * Seed-42 initial conditions of ver7/GSimulation.cpp:45-94, bit-exact and independent of the
  * host's libstdc++: mt19937(42) re-created per array family, libstdc++-11's
  * uniform_real_distribution<float> restated (one 32-bit draw per value).  Host-only (no GPU

@@ -9,6 +9,8 @@
 #include <rccl/rccl.h>  // types and prototypes only: librccl is dlopen'ed (struct Rccl), never linked
 
 #include <algorithm>
+#include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -16,6 +18,7 @@
 #include <vector>
 
 #include "nbx_internal.hpp"
+#include "nbx_watchdog.hpp"
 
 using namespace nbx_detail;
 
@@ -65,6 +68,7 @@ struct Rccl {
 Rccl g_rccl;
 static_assert(std::is_same<decltype(Rccl::AllGather), ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t)>::value,
               "ncclAllGather is called as (send, recv, bytes, ncclChar, comm, stream)");
+static_assert(kExitCollectiveTimeout == NBX_EXIT_COLLECTIVE_TIMEOUT, "include/nbx.h documents the watchdog's exit status");
 static_assert(sizeof(ncclUniqueId) == NBX_UNIQUE_ID_BYTES, "include/nbx.h promises callers the size of the rendezvous token");
 
 }  // namespace
@@ -80,6 +84,9 @@ struct nbx_group {
   double* ke_all = nullptr;          // rank groups: [P] sum m v^2 of every rank, all-gathered
   void* vel_stage = nullptr;         // rank groups, nbx_group_download: own velocities padded to `block` records
   void* vel_all = nullptr;           //   and the all-gathered [P * block] records
+  // watchdog bookkeeping (nbx_watchdog.hpp): steps enqueued since the last host synchronisation, and what one step took
+  long long steps_unsynced = 0;
+  double step_s_est = 0.0;           // seconds per step measured over the last fully synchronised nbx_group_step call; 0 = not yet
 };
 
 namespace {
@@ -95,6 +102,19 @@ void partition(int n, int n_ranks, int* P_out, int* block_out) {
   }
   *P_out = P;
   *block_out = block;
+}
+
+// Seconds of legitimately queued work in front of a synchronisation: the watchdog's deadline is its timeout PLUS this, so
+// that a long print window is not mistaken for a dead peer.  Four times the measured step time once a window has been
+// timed; before that a rate no shape is slower than (2e10 pair/s: the validation kernel runs at ~5e11).
+double queued_allowance(const nbx_group* g) {
+  if (g->steps_unsynced <= 0 || g->rank.empty()) return 0.0;
+  double per_step = 4.0 * g->step_s_est;
+  if (!(per_step > 0.0)) {
+    per_step = 1e-3;
+    for (const nbx_ctx* c : g->rank) per_step += (double)c->i_count * (double)c->n / 2e10;  // logical ranks may share a GPU: add them up
+  }
+  return per_step * (double)g->steps_unsynced;
 }
 
 int rccl_fail(const char* what, ncclResult_t e) { return fail(NBX_ERR_DEVICE, std::string(what) + ": " + g_rccl.text(e)); }
@@ -287,7 +307,12 @@ int nbx_group_create_rank(nbx_group** out, int32_t n, int32_t precision, int32_t
   ncclUniqueId id;
   std::memcpy(&id, unique_id, sizeof id);
   g->comm.assign(1, nullptr);
-  const ncclResult_t e = g_rccl.CommInitRank(&g->comm[0], P, id, rank);
+  Watchdog::instance().set_identity(rank, P);
+  ncclResult_t e;
+  {
+    Watchdog::Scope bounded("ncclCommInitRank (nbx_group_create_rank)");  // blocks until all P ranks have called it
+    e = g_rccl.CommInitRank(&g->comm[0], P, id, rank);
+  }
   if (e != ncclSuccess) { g->comm.clear(); return rccl_fail("ncclCommInitRank", e); }
   g->use_rccl = true;
   owner.g = nullptr;
@@ -299,6 +324,8 @@ int nbx_group_create_rank(nbx_group** out, int32_t n, int32_t precision, int32_t
 
 void nbx_group_destroy(nbx_group* g) {
   if (!g) return;
+  // draining the streams and tearing the communicators down waits for collectives in flight: bounded like the others
+  Watchdog::Scope bounded("nbx_group_destroy (stream synchronisation + ncclCommDestroy)", queued_allowance(g));
   for (nbx_ctx* c : g->rank) if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
   for (auto cm : g->comm) if (cm) (void)g_rccl.CommDestroy(cm);
   for (size_t r = 0; r < g->done.size(); ++r) if (g->done[r]) { (void)hipSetDevice(g->dev[r]); (void)hipEventDestroy(g->done[r]); }
@@ -326,6 +353,9 @@ int nbx_group_step(nbx_group* g, double dt, int32_t nsteps, double* kenergy_out)
   return guarded("nbx_group_step", [&]() -> int {
   if (!g) return fail(NBX_ERR_ARG, "nbx_group_step: group is NULL");
   if (nsteps < 0) return fail(NBX_ERR_ARG, "nbx_group_step: nsteps < 0");
+  const auto t_enter = std::chrono::steady_clock::now();
+  const bool window_from_sync = g->steps_unsynced == 0;  // everything this call waits for was enqueued by this call
+  g->steps_unsynced += nsteps;
   for (int s = 0; s < nsteps; ++s) {
     for (nbx_ctx* c : g->rank) {
       const int rc = nbx_step_local(c, dt);
@@ -342,6 +372,8 @@ int nbx_group_step(nbx_group* g, double dt, int32_t nsteps, double* kenergy_out)
   }
   if (kenergy_out) {
     double sum = 0.0;
+    // the one place a stepping group blocks: every all-gather enqueued above completes only if every rank took part
+    Watchdog::Scope bounded("nbx_group_step (position all-gathers + kinetic energy: stream synchronisation)", queued_allowance(g));
     if (g->my_rank >= 0) {
       // one process per GPU: every rank reduces its partial on the device, one 8-byte all-gather, and all ranks add
       // the P values in rank order -- the same number on every rank, independent of arrival order
@@ -373,6 +405,9 @@ int nbx_group_step(nbx_group* g, double dt, int32_t nsteps, double* kenergy_out)
       }
     }
     *kenergy_out = 0.5 * sum;
+    if (window_from_sync && nsteps > 0)
+      g->step_s_est = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count() / nsteps;
+    g->steps_unsynced = 0;
   }
   return NBX_OK;
   });
@@ -381,6 +416,8 @@ int nbx_group_step(nbx_group* g, double dt, int32_t nsteps, double* kenergy_out)
 int nbx_group_download(nbx_group* g, void* px, void* py, void* pz, void* vx, void* vy, void* vz) {
   return guarded("nbx_group_download", [&]() -> int {
   if (!g) return fail(NBX_ERR_ARG, "nbx_group_download: group is NULL");
+  Watchdog::Scope bounded("nbx_group_download (stream synchronisation + all-gather of the velocities)", queued_allowance(g));
+  struct Synced { nbx_group* g; ~Synced() { g->steps_unsynced = 0; } } synced{g};
   for (nbx_ctx* c : g->rank) {
     const int rc = nbx_sync(c);
     if (rc) return rc;
@@ -424,6 +461,14 @@ int nbx_group_download(nbx_group* g, void* px, void* py, void* pz, void* vx, voi
     const int rc = nbx_download(g->rank[r], r == 0 ? px : nullptr, r == 0 ? py : nullptr, r == 0 ? pz : nullptr, vx, vy, vz);
     if (rc) return rc;
   }
+  return NBX_OK;
+  });
+}
+
+int nbx_collective_timeout(double seconds) {
+  return guarded("nbx_collective_timeout", [&]() -> int {
+  if (std::isnan(seconds)) return fail(NBX_ERR_ARG, "nbx_collective_timeout: seconds is NaN");
+  Watchdog::instance().set_timeout(seconds);
   return NBX_OK;
   });
 }

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <iomanip>
 #include <iostream>
+#include <vector>
 
 #include "../../include/nbx.h"
 #include "cpu_time.hpp"
@@ -198,6 +199,9 @@ void GSimulation::print_header() {
 void GSimulation::start() {
   const int n = get_npart();
   const int nsteps = get_nsteps();
+  // NBODY_SFREQ=<k>: print (and synchronise) every k steps instead of the reference's fixed 50 (_sfreq, ver7/GSimulation.cpp:31,
+  // set only by its constructor) -- bench.py's native cross-check uses short windows
+  if (env_int("NBODY_SFREQ", 0) > 0) set_sfreq(env_int("NBODY_SFREQ", 0));
   const int sfreq = get_sfreq();
   const double dt = (double)get_tstep();
   require_world();
@@ -280,6 +284,12 @@ void GSimulation::start() {
                 << world_size << ")" << std::endl;
       std::exit(1);
     }
+    // NBODY_COLLECTIVE_TIMEOUT (seconds; default 120, 0 = off): libnbx's watchdog on the blocking collectives below --
+    // a rank whose peer died after the rendezvous ends with status NBX_EXIT_COLLECTIVE_TIMEOUT instead of hanging in
+    // ncclCommInitRank or in a window's synchronisation (the reference's MPI mode hangs: ver5_all/GSimulation.cpp:170-214)
+    if (const char* ct = std::getenv("NBODY_COLLECTIVE_TIMEOUT")) {
+      if (*ct && nbx_collective_timeout(std::atof(ct))) die_nbx("nbx_collective_timeout");
+    }
     char token[NBX_UNIQUE_ID_BYTES];
     std::memset(token, 0, sizeof token);
     const bool token_ok = !root || nbx_comm_unique_id(token) == NBX_OK;
@@ -313,6 +323,8 @@ void GSimulation::start() {
   const double gflops = 1e-9 * ((11. + 18.) * nd * nd + nd * 19.);  // the reference's flop model
   double av = 0.0, dev = 0.0;
   int nf = 0;
+  struct Window { int step; double kenergy, seconds; };
+  std::vector<Window> windows;  // for NBODY_JSON: every printed row at full precision
 
   CPUTime time;
   const double t0 = time.start();
@@ -335,6 +347,7 @@ void GSimulation::start() {
     _kenergy = (real_type)ke;
     nf += 1;
     const double wt = w1 - w0;
+    windows.push_back(Window{done, ke, wt});
     if (root)
       std::cout << " " << std::left << std::setw(8) << done << std::left << std::setprecision(5) << std::setw(8)
               << done * get_tstep() << std::left << std::setprecision(5) << std::setw(12) << _kenergy << std::left
@@ -403,10 +416,18 @@ void GSimulation::start() {
       std::fprintf(jf,
                    "{\"n\": %d, \"steps\": %d, \"precision\": %d, \"ranks\": %d, \"exchange\": \"%s\", \"total_time_s\": %.9g, "
                    "\"pair_per_s_total\": %.9g, \"gflops_avg_reference_convention\": %s, \"kenergy_last_printed\": %.17g, "
-                   "\"kernel\": \"%s\", \"bodies_per_lane\": %d, \"j_split\": %d, \"grid\": [%d, %d], \"device\": \"%s\"}\n",
+                   "\"kernel\": \"%s\", \"bodies_per_lane\": %d, \"j_split\": %d, \"grid\": [%d, %d], \"device\": \"%s\", "
+                   "\"one_process_per_rank\": %s, \"uses_rccl\": %s, \"windows\": [",
                    n, nsteps, st.precision, (int)ranks, ranks > 1 ? (rccl ? "rccl" : "copy") : "none", _totTime, pps, avtxt,
                    (double)_kenergy, kernel_name(st.kernel_variant),
-                   st.bodies_per_lane, st.j_split, st.force_grid_x, st.force_grid_y, st.device_name);
+                   st.bodies_per_lane, st.j_split, st.force_grid_x, st.force_grid_y, st.device_name, _multiprocess ? "true" : "false",
+                   rccl ? "true" : "false");
+      // every printed row: the step, the energy as computed (fp64 sum of the ranks' partials, before the narrowing to
+      // real_type that the table shows) and the window's wall time
+      for (size_t k = 0; k < windows.size(); ++k)
+        std::fprintf(jf, "%s{\"step\": %d, \"kenergy\": %.17g, \"seconds\": %.9g}", k ? ", " : "", windows[k].step, windows[k].kenergy,
+                     windows[k].seconds);
+      std::fprintf(jf, "]}\n");
       std::fclose(jf);
     }
   }

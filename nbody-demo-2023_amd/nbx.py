@@ -24,7 +24,7 @@ SYMBOLS = (
     "nbx_step_trace", "nbx_step_local", "nbx_exchange_buffer", "nbx_commit", "nbx_kenergy_partial",
     "nbx_accel", "nbx_sync", "nbx_download", "nbx_ic_pos", "nbx_ic_vel", "nbx_ic_mass", "nbx_profile",
     "nbx_stats", "nbx_group_create", "nbx_group_destroy", "nbx_group_upload", "nbx_group_step", "nbx_group_download",
-    "nbx_group_info", "nbx_partition", "nbx_comm_unique_id", "nbx_group_create_rank",
+    "nbx_group_info", "nbx_partition", "nbx_comm_unique_id", "nbx_group_create_rank", "nbx_collective_timeout",
 )
 
 
@@ -114,6 +114,7 @@ def load():
     L.nbx_partition.argtypes = [i32, i32, i32] + [ctypes.POINTER(i32)] * 5
     L.nbx_comm_unique_id.argtypes = [vp]
     L.nbx_group_create_rank.argtypes = [ctypes.POINTER(vp), i32, i32, i32, i32, vp, i32, ctypes.POINTER(Opts)]
+    L.nbx_collective_timeout.argtypes = [dbl]
     _lib = L
     return L
 
@@ -308,6 +309,14 @@ def unique_id():
     buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
     _check(load().nbx_comm_unique_id(buf), "nbx_comm_unique_id")
     return buf.raw
+
+
+EXIT_COLLECTIVE_TIMEOUT = 75
+
+
+def collective_timeout(seconds):
+    """nbx_collective_timeout: the watchdog's bound on blocking group collectives (<= 0: off)."""
+    _check(load().nbx_collective_timeout(float(seconds)), "nbx_collective_timeout")
 
 
 def partition(n, n_ranks, rank):

@@ -51,6 +51,48 @@ def check_world(n, world, align=BLOCK_ALIGN):
                          "launch at most %d ranks" % (n, used, block, world, world - used, used))
 
 
+def _stat3(xs):
+    xs = [float(x) for x in xs]
+    return {"min": min(xs), "mean": sum(xs) / len(xs), "max": max(xs)} if xs else None
+
+
+def gather_rank_reports(dist, report):
+    """Every rank contributes one dict; every rank gets the list in rank order (all_gather_object: works over RCCL and gloo)."""
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, report)
+    return out
+
+
+def summarise_rank_reports(reports, block_bytes):
+    """bench.py's N > 1 breakdown from the per-rank reports (dicts with rank, device, force_ms_mean, allgather_ms (list),
+    elapsed_s, bodies_owned): min / mean / max over ranks of the force kernel and of the all-gather, and the skew.
+
+    allgather_ms on a rank = the collective + the wait for the slowest rank (see ShardedSimulation.profile_exchange), so
+    its minimum over ranks estimates the collective alone and `skew_ms` (slowest minus fastest force kernel) says how much
+    of the rest is waiting.  What the reference does at this point -- nine n-float broadcasts and three gathers through
+    rank 0 per step, ver5_all/GSimulation.cpp:170-214 -- has no breakdown at all."""
+    world = len(reports)
+    reports = sorted(reports, key=lambda r: r["rank"])
+    if [r["rank"] for r in reports] != list(range(world)):
+        raise ValueError("rank reports do not cover 0..%d exactly once: %r" % (world - 1, [r["rank"] for r in reports]))
+    force = [r["force_ms_mean"] for r in reports]
+    ag_mean = [sum(r["allgather_ms"]) / len(r["allgather_ms"]) if r["allgather_ms"] else 0.0 for r in reports]
+    ag_max = [max(r["allgather_ms"]) if r["allgather_ms"] else 0.0 for r in reports]
+    return {
+        "world_seen": world,
+        "force_kernel_ms": _stat3(force),
+        "allgather_ms_per_step": _stat3(ag_mean),
+        "allgather_ms_worst_step": max(ag_max) if ag_max else None,
+        "skew_ms": max(force) - min(force),
+        "slowest_rank": max(range(world), key=lambda r: force[r]),
+        "elapsed_s": _stat3([r["elapsed_s"] for r in reports]),
+        "bytes_gathered_per_step": block_bytes * (world - 1),  # received by every rank: the other ranks' blocks
+        "bytes_sent_per_step": block_bytes,
+        "per_rank": [{"rank": r["rank"], "device": r.get("device"), "host": r.get("host"), "bodies_owned": r.get("bodies_owned"),
+                      "force_ms": r["force_ms_mean"], "allgather_ms": a} for r, a in zip(reports, ag_mean)],
+    }
+
+
 class _DeviceBuffer:
     """Zero-copy view of a raw device pointer for torch.as_tensor (__cuda_array_interface__)."""
 
@@ -148,6 +190,7 @@ class ShardedSimulation:
         self.bytes_gathered = 0
         self._staged = False      # out-of-place fallback of the all-gather (see _all_gather_in_place)
         self._stage_buf = None
+        self._xprof = None        # profile_exchange(True): per-step durations of the all-gather on this rank
 
     def upload(self, state):
         self.engine.upload(state)
@@ -178,12 +221,51 @@ class ShardedSimulation:
             full.copy_(self._stage_buf)
         self.bytes_gathered += nb * (self.world - 1)
 
+    def profile_exchange(self, enable=True):
+        """Time every all-gather from now on (bench.py's N > 1 breakdown).  On a device buffer over "nccl" the bracket
+        is a pair of events on the stream the force kernel and the collective are ordered on: the start fires when this
+        rank's force launch has finished, the end when the gathered array is complete -- the collective itself PLUS the
+        wait for the slowest rank.  The smallest value over the ranks is therefore the collective's own cost, the spread
+        the skew.  Anything else (CPU rehearsals, the host-staged gloo rehearsal) is timed on the host clock after
+        draining this rank's own work."""
+        self._xprof = {"events": [], "host_ms": []} if enable else None
+
+    def exchange_ms(self):
+        """Per-step all-gather durations recorded since profile_exchange(True), in milliseconds (synchronises)."""
+        if not self._xprof:
+            return []
+        out = list(self._xprof["host_ms"])
+        if self._xprof["events"]:
+            import torch
+            torch.cuda.synchronize()
+            out += [a.elapsed_time(b) for a, b in self._xprof["events"]]
+        return out
+
+    def _exchange(self):
+        full = self.engine.exchange_tensor()
+        xp = self._xprof
+        if xp is None:
+            return self._all_gather_in_place(full)
+        import time
+        import torch
+        if full.is_cuda and self.dist.get_backend() == "nccl":
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            self._all_gather_in_place(full)
+            b.record()
+            xp["events"].append((a, b))
+        else:
+            self.engine.sync()
+            t0 = time.perf_counter()
+            self._all_gather_in_place(full)
+            xp["host_ms"].append(1e3 * (time.perf_counter() - t0))
+
     def step(self, nsteps=1, dt=None):
         dt = _nbx().DT if dt is None else dt
         for _ in range(nsteps):
             self.engine.step_local(dt)
             if self.dist:
-                self._all_gather_in_place(self.engine.exchange_tensor())
+                self._exchange()
             self.engine.commit()
             self.steps_done += 1
 

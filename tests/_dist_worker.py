@@ -90,10 +90,18 @@ def main():
     ic = O.init_state(n)
     sim.upload({f: getattr(ic, f) for f in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass")})
     ke = []
+    sim.profile_exchange(True)  # bench.py's N > 1 breakdown: every all-gather timed on every rank ...
     for _ in range(steps):
         sim.step(1, dt=float(O.DT_F32))
         ke.append(sim.kenergy())
     pos = sim.engine.positions()
+    xms = sim.exchange_ms()
+    # ... and gathered to rank 0 (all ranks receive the list; rank 0 writes the summary the bench line carries)
+    reports = sharded.gather_rank_reports(dist, {"rank": rank, "device": None, "host": "cpu", "bodies_owned": sim.i_count,
+                                                 "force_ms_mean": 1.0 + rank, "allgather_ms": xms, "elapsed_s": 0.5 + rank})
+    if rank == 0:
+        with open(out + ".summary", "w") as f:
+            json.dump({"summary": sharded.summarise_rank_reports(reports, sim.block * sim.rec), "n_reports": len(reports)}, f)
     res = {"rank": rank, "world": world, "ke": ke, "i_begin": sim.i_begin, "i_count": sim.i_count,
            "block": sim.block, "n_alloc": sim.n_alloc, "bytes_gathered": sim.bytes_gathered,
            "pos_crc": int(np.frombuffer(pos.tobytes(), dtype=np.uint32).sum() & 0xFFFFFFFF)}

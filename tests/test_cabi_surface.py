@@ -178,6 +178,7 @@ def test_every_entry_point_rejects_null_and_nonsense_without_aborting(nbx):
                                   lambda: L.nbx_group_create_rank(ctypes.byref(h), 10, 32, 2, 2, buf, -1, None),
                                   lambda: L.nbx_group_create_rank(ctypes.byref(h), 10, 32, 1, 0, null, -1, None),
                                   lambda: L.nbx_group_create_rank(ctypes.byref(h), 300, 32, 3, 0, buf, -1, None)],  # rank 2 would be empty
+        "nbx_collective_timeout": [lambda: L.nbx_collective_timeout(float("nan"))],
     }
     # the remaining symbols cannot fail: they are exercised for "does not crash on NULL"
     L.nbx_destroy(null)

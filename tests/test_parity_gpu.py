@@ -744,7 +744,10 @@ def test_bench_line_schema_and_roofline_floor():
     assert r["frac"] > 0.40, r["frac"]                       # north_star target at n = 262144
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 1e8 and c["unit"] == "pair/s"
+    assert c["cores_on_box"] >= c["cores"]
     assert d["parity"]["max_rel_kenergy_err"] < 1e-4
+    # traffic is reported only for the launch shape the committed PMC profile was taken on
+    assert (r["traffic"] is not None) == (r["traffic_profiled_shape"] == r["traffic_shape_ran"]) and r["traffic_note"]
 
 
 def test_cli_snapshot_and_restart(nbx, tmp_path):
@@ -1404,6 +1407,36 @@ def test_cli_one_process_per_gpu_mode_with_a_world_of_one(tmp_path):
     assert json.load(open(out))["exchange"] == "none"  # a single rank: nothing to exchange with
 
 
+def test_rank_whose_peer_left_after_the_rendezvous_ends_with_status_75(tmp_path):
+    """VERDICT r2 item 3 on the GPU: nbody.x as rank 0 of a world of two; "rank 1" is the rendezvous test driver, which says
+    its hello, receives the RCCL token and exits -- a rank that died right after the rendezvous.  Rank 0 then sits alone in
+    ncclCommInitRank (no kernel is in flight at that point).  The reference's MPI mode would wait for ever; here libnbx's
+    watchdog ends the process with NBX_EXIT_COLLECTIVE_TIMEOUT and names the call."""
+    import socket
+    import subprocess
+    import time
+    host = os.path.join(ROOT, "nbody-demo-2023_amd", "host")
+    drv = str(tmp_path / "rendezvous_driver.x")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I", host, os.path.join(ROOT, "tests", "rendezvous_driver.cpp"), "-o", drv, "-lpthread"])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    env = dict(os.environ, NBODY_WORLD="2", NBODY_RANK="0", NBODY_MASTER_PORT=port, NBODY_COLLECTIVE_TIMEOUT="6", NBODY_RENDEZVOUS_TIMEOUT="60")
+    t0 = time.time()
+    p0 = subprocess.Popen([os.path.join(host, "nbody.x"), "3000", "100"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    p1 = subprocess.run([drv, "1", "2", port, "3000", "60"], capture_output=True, text=True, timeout=120)  # signature (3000, 100, 32)
+    assert p1.returncode == 0 and p1.stdout.startswith("ok "), (p1.stdout, p1.stderr)
+    out, err = p0.communicate(timeout=120)
+    assert p0.returncode == nbx_exit_collective_timeout(), (p0.returncode, err[-2000:])
+    assert "rank 0 of 2 has been inside ncclCommInitRank" in err and "a peer rank is gone or never arrived" in err
+    assert time.time() - t0 < 90
+
+
+def nbx_exit_collective_timeout():
+    return 75  # NBX_EXIT_COLLECTIVE_TIMEOUT (include/nbx.h; tests/test_watchdog.py checks the header)
+
+
 # ---- bench.py's N > 1 path, rehearsed on the one GPU: same launcher line as the driver's ----------------------------------
 def _bench_under_torchrun(nproc, extra_env, args, port):
     import subprocess
@@ -1430,6 +1463,20 @@ def test_bench_n_gt_1_path_with_two_ranks_sharing_the_gpu(nbx):
         c.upload(nbx.initial_conditions(n))
         ke = c.step(steps + warmup)
     assert rel_err(line["kenergy_after_run"], ke) < 1e-6, (line["kenergy_after_run"], ke)
+    # an N > 1 line validates itself -- parity of this very multi-rank form against the reference's trace ...
+    par = line["parity"]
+    assert par["fixture"] == "ver7_f32_n16384_s500.json" and par["steps"] == 10 and par["ranks"] == 2
+    assert par["pass"] and par["max_rel_kenergy_err"] < 1e-4 and len(par["rel_kenergy_err_per_step"]) == 10
+    # ... and says what every rank did
+    rk = line["ranks"]
+    assert rk["world_seen"] == 2 and rk["backend"].startswith("gloo") and [r["rank"] for r in rk["per_rank"]] == [0, 1]
+    assert [r["bodies_owned"] for r in rk["per_rank"]] == [n // 2, n // 2] and all(r["device"] == 0 for r in rk["per_rank"])
+    assert rk["bytes_gathered_per_step"] == (n // 2) * 16 == rk["bytes_sent_per_step"]
+    f, g = rk["force_kernel_ms"], rk["allgather_ms_per_step"]
+    assert 0 < f["min"] <= f["mean"] <= f["max"] and 0 < g["min"] <= g["mean"] <= g["max"] <= rk["allgather_ms_worst_step"]
+    assert rk["skew_ms"] == pytest.approx(f["max"] - f["min"]) and 0 < rk["allgather_share_of_step"] < 1
+    assert "skipped" in line["native_rank_group"]  # RCCL cannot form a communicator of two ranks on one device
+    assert line["roofline"]["traffic"] is None and line["roofline"]["traffic_note"]
 
 
 def test_bench_n_gt_1_path_over_rccl_with_a_world_of_one(nbx):
@@ -1442,4 +1489,17 @@ def test_bench_n_gt_1_path_over_rccl_with_a_world_of_one(nbx):
     with nbx.Context(n, 32) as c:
         c.upload(nbx.initial_conditions(n))
         ke = c.step(steps + warmup)
+        c.upload(nbx.initial_conditions(n))
+        ke10 = c.step(10)
     assert rel_err(line["kenergy_after_run"], ke) < 1e-6, (line["kenergy_after_run"], ke)
+    rk = line["ranks"]
+    assert rk["world_seen"] == 1 and rk["backend"].startswith("nccl") and rk["bytes_gathered_per_step"] == 0
+    assert rk["allgather_ms_per_step"]["mean"] > 0 and rk["force_kernel_ms"]["mean"] > 0 and rk["skew_ms"] == 0
+    assert line["parity"]["pass"] and line["parity"]["ranks"] == 1
+    # the drop-in's own multi-process path (nbody.x: nbx_group_create_rank + in-place ncclAllGather inside libnbx) ran as a
+    # child on the same GPU and agrees with the torch.distributed path of the line
+    nat = line["native_rank_group"]
+    assert nat["returncodes"] == [0] and nat["uses_rccl"] and nat["one_process_per_rank"] and nat["ms_per_step"] > 0, nat
+    assert nat["kenergy_equal_to_torch_path"] and nat["rel_diff_vs_torch_path"] < 1e-12
+    assert rel_err(nat["kenergy_step10"], ke10) < 1e-12
+    assert nat["rel_kenergy_err_vs_reference_step10"] < 1e-4

@@ -65,6 +65,32 @@ def test_gloo_ranks_reproduce_single_process_trace(oracle, tmp_path, n, world, s
         assert res[r]["ke"] == res[0]["ke"]
         assert res[r]["bytes_gathered"] == steps * (world - 1) * res[r]["block"] * 16
     assert sum(x["i_count"] for x in res) == n
+    # the gather-to-rank-0 breakdown of bench.py's N > 1 line: every rank reported, in rank order
+    summ = json.load(open(out + ".summary"))
+    assert summ["n_reports"] == world
+    b = summ["summary"]
+    assert b["world_seen"] == world and [r["rank"] for r in b["per_rank"]] == list(range(world))
+    assert [r["bodies_owned"] for r in b["per_rank"]] == [x["i_count"] for x in res]
+    assert b["force_kernel_ms"] == {"min": 1.0, "mean": (world + 1) / 2.0, "max": float(world)} and b["skew_ms"] == world - 1.0
+    assert b["slowest_rank"] == world - 1
+    assert b["bytes_gathered_per_step"] == (world - 1) * res[0]["block"] * 16 and b["bytes_sent_per_step"] == res[0]["block"] * 16
+    ag = b["allgather_ms_per_step"]
+    assert 0.0 < ag["min"] <= ag["mean"] <= ag["max"] <= b["allgather_ms_worst_step"]
+    assert all(r["allgather_ms"] > 0.0 for r in b["per_rank"])
+
+
+def test_rank_report_summary_arithmetic():
+    """summarise_rank_reports is plain arithmetic: check it without any process group (and that a missing rank is an error)."""
+    import sharded
+    reps = [{"rank": 1, "device": 1, "host": "h", "bodies_owned": 100, "force_ms_mean": 32.0, "allgather_ms": [0.5, 0.7], "elapsed_s": 1.0},
+            {"rank": 0, "device": 0, "host": "h", "bodies_owned": 128, "force_ms_mean": 30.0, "allgather_ms": [2.5, 2.9], "elapsed_s": 1.1}]
+    b = sharded.summarise_rank_reports(reps, 4096)
+    assert b["force_kernel_ms"] == {"min": 30.0, "mean": 31.0, "max": 32.0} and b["skew_ms"] == 2.0 and b["slowest_rank"] == 1
+    assert abs(b["allgather_ms_per_step"]["min"] - 0.6) < 1e-12 and abs(b["allgather_ms_per_step"]["max"] - 2.7) < 1e-12
+    assert b["allgather_ms_worst_step"] == 2.9 and b["bytes_gathered_per_step"] == 4096
+    assert [r["device"] for r in b["per_rank"]] == [0, 1]
+    with pytest.raises(ValueError):
+        sharded.summarise_rank_reports([reps[0], dict(reps[0])], 4096)
 
 
 def test_world_too_large_for_n_is_refused_on_every_rank(tmp_path):

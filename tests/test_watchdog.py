@@ -1,0 +1,114 @@
+"""The bound on blocking collectives (csrc/nbx_watchdog.hpp, nbx_collective_timeout) -- CPU only.
+
+The reference's MPI mode hangs for ever when a rank dies (ver5_all/GSimulation.cpp:93-115,170-214).  Here every blocking
+group collective is watched by a host thread that ends the process with status 75 and says which call was stuck.  The
+collectives themselves need GPUs (tests/test_parity_gpu.py runs nbody.x against a peer that leaves after the rendezvous);
+what runs anywhere is the watchdog itself, with a read on a pipe nobody writes to standing in for the stuck call, and the
+real rendezvous of nbody.x in front of it.
+"""
+import math
+import os
+import socket
+import subprocess
+import time
+
+import pytest
+
+from conftest import PKG, ROOT
+
+HOST = os.path.join(PKG, "host")
+CSRC = os.path.join(PKG, "csrc")
+EXIT = 75
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("wd") / "watchdog_driver.x")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", HOST, "-I", CSRC, os.path.join(ROOT, "tests", "watchdog_driver.cpp"),
+                           "-o", exe, "-lpthread"])
+    return exe
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_a_call_that_never_returns_ends_the_process_with_75_and_names_the_call(driver):
+    t0 = time.time()
+    p = subprocess.run([driver, "stuck", "2"], capture_output=True, text=True, timeout=60)
+    dt = time.time() - t0
+    assert p.returncode == EXIT
+    assert 1.9 < dt < 8
+    assert "rank 0 of 2 has been inside ncclCommInitRank (test stand-in)" in p.stderr and "status 75" in p.stderr
+
+
+def test_calls_that_return_in_time_are_left_alone(driver):
+    p = subprocess.run([driver, "ok", "2"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and p.stdout.strip() == "done" and p.stderr == ""
+
+
+def test_timeout_zero_switches_the_watchdog_off(driver):
+    p = subprocess.run([driver, "off"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and p.stdout.strip() == "done"
+
+
+def test_queued_work_extends_the_deadline(driver):
+    """A print window that legitimately takes longer than the timeout is not a dead peer: limit = timeout + allowance."""
+    p = subprocess.run([driver, "allowance", "1", "4", "2.5"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and p.stdout.strip() == "done"
+    p = subprocess.run([driver, "allowance", "1", "0.5", "30"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == EXIT and "a long print window" in p.stderr and "limit 2 s" in p.stderr
+
+
+def test_inner_scopes_do_not_push_the_outer_deadline_back(driver):
+    t0 = time.time()
+    p = subprocess.run([driver, "nested", "2"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == EXIT and time.time() - t0 < 8
+    assert "rank 1 of 4 has been inside outer call" in p.stderr
+
+
+def test_rank_that_dies_after_the_rendezvous_does_not_leave_rank_zero_hanging(driver):
+    """VERDICT r2 item 3 on CPU: two processes complete nbody.x's rendezvous; rank 1 then exits (a rank that died); rank 0
+    enters the collective alone and ends non-zero within the timeout instead of waiting for ever."""
+    port = str(_free_port())
+    t0 = time.time()
+    p0 = subprocess.Popen([driver, "rdv", "0", "2", port, "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(0.3)
+    p1 = subprocess.Popen([driver, "rdv", "1", "2", port, "3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    o1, _ = p1.communicate(timeout=60)
+    o0, e0 = p0.communicate(timeout=60)
+    assert p1.returncode == 0 and "rendezvous ok" in o1
+    assert "rendezvous ok" in o0
+    assert p0.returncode == EXIT and "ncclCommInitRank" in e0 and "a peer rank is gone or never arrived" in e0
+    assert time.time() - t0 < 15
+
+
+def test_library_entry_point(nbx):
+    """nbx_collective_timeout is host-only: callable without a GPU; NaN is refused; the setting is process-wide."""
+    nbx.collective_timeout(30)
+    nbx.collective_timeout(0)
+    nbx.collective_timeout(-1)
+    with pytest.raises(nbx.NbxError) as e:
+        nbx.collective_timeout(math.nan)
+    assert e.value.code == nbx.NBX_ERR_ARG
+    nbx.collective_timeout(120)
+    assert nbx.EXIT_COLLECTIVE_TIMEOUT == EXIT
+    hdr = open(os.path.join(ROOT, "include", "nbx.h")).read()
+    assert "#define NBX_EXIT_COLLECTIVE_TIMEOUT 75" in hdr
+
+
+def test_watchdog_under_thread_sanitizer(tmp_path):
+    """arm / disarm race against the watcher thread 20000 times: no data race, no lost wake-up."""
+    exe = str(tmp_path / "wd_tsan.x")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I", HOST, "-I", CSRC, os.path.join(ROOT, "tests", "watchdog_driver.cpp"),
+                        "-o", exe, "-lpthread"], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime in this image: " + r.stderr[-200:])
+    p = subprocess.run([exe, "ok", "1"], capture_output=True, text=True, timeout=300)
+    if "FATAL: ThreadSanitizer" in p.stderr and "mmap" in p.stderr.lower():
+        pytest.skip("ThreadSanitizer cannot map its shadow here")
+    assert p.returncode == 0 and "data race" not in p.stderr and p.stdout.strip() == "done", p.stderr[-2000:]
