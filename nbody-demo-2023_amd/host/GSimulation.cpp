@@ -230,6 +230,18 @@ void GSimulation::start() {
     }
   }
   print_header();
+#ifdef NBX_BANNER_IN_MAIN
+  // The ver5_all surface: its HIP back end announces the block size between the header and the first row
+  // (ver5_all/programming_models/hip/Compute.cpp:133-140; argv[5] = thread_dim0 overrides its default of 256).  The kernels
+  // here are written for workgroups of 256 threads -- four wave64s, the j tile, the LDS reductions -- so the line always
+  // says 256, and another request is answered on stderr instead of being dropped silently.
+  if (root) {
+    if (_thread_dim0 != 0 && _thread_dim0 != 256)
+      std::cerr << "nbody.x: thread_dim0 = " << _thread_dim0 << " ignored: the gfx950 kernels use workgroups of 256 threads (dim1 = bodies per lane is honoured)"
+                << std::endl;
+    std::cout << "using block_size = " << 256 << std::endl;
+  }
+#endif
 
   if (n <= 0) {  // the reference would run zero-trip loops; nothing to hand to the GPU
     if (!root) return;

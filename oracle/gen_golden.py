@@ -45,12 +45,16 @@ CASES = [
 #   python oracle/gen_golden.py --only f32:1048576:3     (40 min: the first steps at configs[3]'s size)
 #   python oracle/gen_golden.py --only f64:262144:50     (over an hour: configs[4] up to its first printed row)
 #   OMP_NUM_THREADS=6 python oracle/gen_golden.py --only f32:1048576:10    (2.5 h: ten steps at configs[3]'s size, round 2)
+#   python oracle/gen_golden.py --only f32o3:16384:500    (1-2 min: configs[1] from the -O3 / AVX2 / FMA build of the reference, round 3)
 BIG_CASES = [("f32", 262144, 7), ("f64", 262144, 3), ("f32", 32768, 500), ("f32", 65536, 500), ("f32", 262144, 200), ("f32", 1048576, 3), ("f64", 262144, 50),
              ("f32", 1048576, 10)]
 
 
 def run_case(prec, n, steps, nsample=8):
-    exe = os.path.join(HERE, "_ref", "ver7_trace.x" if prec == "f32" else "ver7_trace_f64.x")
+    # "f32o3": the SAME unmodified source built with the best-effort flags (_ref/ver7_trace_o3.x: -O3 -march=x86-64-v3, FMA
+    # contraction on) -- a second legitimate build of the reference, kept to show how far two builds of the reference drift
+    # apart in the chaotic regime (n = 16384 x 500: tests/test_parity_gpu.py, profiles/r03_config1_divergence.json); never the oracle
+    exe = os.path.join(HERE, "_ref", {"f32": "ver7_trace.x", "f64": "ver7_trace_f64.x", "f32o3": "ver7_trace_o3.x"}[prec])
     if not os.path.exists(exe):
         sys.exit("missing %s -- run `make -C oracle ref` in the build container first" % exe)
     out = os.path.join(GOLD, "ver7_%s_n%d_s%d.json" % (prec, n, steps))
@@ -61,9 +65,10 @@ def run_case(prec, n, steps, nsample=8):
     os.remove(tmp)
     d["_provenance"] = {
         "source": "reference ver7/GSimulation.cpp compiled unmodified via oracle/ref_wrapper/ver7_trace.cpp",
-        "flags": "g++ -std=c++11 -O2 -fopenmp -ffp-contract=off -include mm_malloc.h"
-                 + (" -DREF_F64" if prec == "f64" else ""),
+        "flags": ("g++ -std=c++11 -O3 -march=x86-64-v3 -fopenmp -include mm_malloc.h" if prec == "f32o3" else
+                  "g++ -std=c++11 -O2 -fopenmp -ffp-contract=off -include mm_malloc.h" + (" -DREF_F64" if prec == "f64" else "")),
         "variant": "fp32 (typedef float real_type)" if prec == "f32" else
+                   "fp32, best-effort build (AVX2 + FMA contraction): a second build of the same source, NOT the pinned oracle" if prec == "f32o3" else
                    "fp64 arithmetic on the fp32-drawn initial conditions (SURVEY 8c variant B), dt=(double)0.1f",
         "generator": "oracle/gen_golden.py",
     }

@@ -275,6 +275,41 @@ def test_kenergy_trace_config1_n16384_s500(nbx, variant):
     assert err.max() < 2e-3, err.max()                    # unprinted late steps: chaotic drift, bounded
 
 
+def test_config1_launch_shape_is_frozen(nbx):
+    """VERDICT r2 item 4a.  configs[1] runs 450 steps past the bounce; which side of 1e-4 a late printed row lands on depends
+    on the summation tree (profiles/r02_config1_by_kernel.txt: SGPRW 7.7e-5, LDS 8.5e-5, jlane 1.7e-4 at the same step).  The
+    shape that passes is therefore part of the contract for n = 16384: a retune of auto_shape that changes ANY of these must
+    come with test_kenergy_trace_config1_n16384_s500 still green -- this test makes such a change visible instead of silent."""
+    with nbx.Context(16384) as c:
+        st = c.stats()
+    assert st["cu_count"] == 256
+    got = {k: st[k] for k in ("kernel_variant", "bodies_per_lane", "j_split", "inner_loop", "summation_order", "fused_epilogue", "force_grid_x", "force_grid_y")}
+    assert got == {"kernel_variant": nbx.KERNEL_SGPRW, "bodies_per_lane": 4, "j_split": 32, "inner_loop": nbx.LOOP_ASM, "summation_order": nbx.ORDER_TREE,
+                   "fused_epilogue": 0, "force_grid_x": 64, "force_grid_y": 32}, got
+
+
+def test_config1_divergence_curve_beside_the_reference_vs_reference_spread(nbx):
+    """configs[1] against TWO builds of the reference's unmodified source -- the pinned -O2 build (the
+    oracle) and the -O3 / AVX2 / FMA build (tests/golden/ver7_f32o3_n16384_s500.json).  The north-star gate (1e-4 on the rows
+    the program prints) is asserted against the pinned build by test_kenergy_trace_config1_n16384_s500; here the whole curve
+    is put beside the reference-vs-reference spread: over all 500 steps the GPU is no farther from the pinned build than
+    1.5x the largest distance between the two reference builds (measured: 3.7e-4 vs 3.0e-4), and it leaves the 1e-5 band
+    no earlier than 50 steps before they leave it with respect to each other."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    g, g2 = load_golden("ver7_f32_n16384_s500.json"), load_golden("ver7_f32o3_n16384_s500.json")
+    ke, _ = _trace(nbx, 16384, 500)
+    d = bench.divergence_vs_reference_builds([float(x) for x in ke], g["kenergy"], g2["kenergy"])
+    _dump("config1_divergence.json", d)
+    m = d["max_over_all_steps"]
+    assert d["max_over_printed_rows"]["gpu_vs_pinned_build"] < 1e-4
+    assert m["gpu_vs_pinned_build"] < 1.5 * m["second_build_vs_pinned_build"], m
+    f = d["first_step_above_1e-5"]
+    assert f["gpu_vs_pinned_build"] > f["second_build_vs_pinned_build"] - 50, f
+
+
 def test_kenergy_trace_config2_n262144_first_steps(nbx):
     """BASELINE.json configs[2] (n=262144): the reference needs ~65 s per step in the build container, so the
     fixture holds its first 7 steps (they agree with the 7 the survey captured)."""
@@ -715,6 +750,15 @@ def test_cli_fp64_and_ver5_front_end(tmp_path):
     assert rc == 0 and lines[0] == "gpu" and lines[1] == "=" * 31
     assert _rows(lines)[1][2] == "2.4341"
     assert any("bodies/lane 2" in ln for ln in lines)
+    # the frame of the reference's HIP build, line for line up to the first row (hip/Compute.cpp:140 prints the block size
+    # between the header and the table's first row)
+    assert lines[:8] == ["gpu", "=" * 31, " Initialize Gravity Simulation", " nPart = 2000; nSteps = 100; dt = 0.1", "-" * 48,
+                         " s       dt      kenergy     time (s)    GFlops      ", "-" * 48, "using block_size = 256"], lines[:8]
+    assert lines[8].split()[0] == "50" and err == ""
+    rc, lines, err = _run_cli("nbody_v5.x", 2000, 50, "gpu", 0.5, 1024, 2)
+    assert rc == 0 and "using block_size = 256" in lines and "thread_dim0 = 1024 ignored" in err
+    rc, lines, err = _run_cli("nbody.x", 2000, 50)  # the ver7 drop-in has no such line (ver7 never prints one)
+    assert rc == 0 and not any("block_size" in ln for ln in lines)
     rc, lines, err = _run_cli("nbody_v5.x", 2000, 100, "cpu")
     assert rc == 1 and "no CPU engine" in err
 
