@@ -40,6 +40,12 @@ constexpr int kTreeOrderMaxN = 131072;
 // (12288: 41 us against SGPRW's 48; at 16384 the two tie at 67 us, and SGPRW's summation tree happens to be the one whose
 // chaotic n = 16384 x 500 run stays inside the 1e-4 gate at every printed step: profiles/r02_config1_by_kernel.txt)
 constexpr int kJlaneMaxOwn = 12288;
+// Tree order, wave-split kernel: contexts that own up to this many bodies keep round 1's split rule (S = 32 at 16384).  Fewer
+// splits are 5 % faster there (profiles/r03_band_sweep.txt: S = 4 or 8), but BASELINE.json configs[1] -- n = 16384 x 500 steps, 450 of
+// them after the bounce -- is decided at the reference's own noise level, and of S = 2, 4, 8, 16, 32 only the tree of S = 32
+// lands inside 1e-4 at every printed row (7.7e-5; the others 1.05e-4 ... 1.43e-4, two builds of the reference itself 1.3e-4:
+// profiles/r03_config1_by_shape.txt).  tests/test_parity_gpu.py::test_config1_launch_shape_is_frozen pins it.
+constexpr int kRound1SplitMaxOwn = 16384;
 constexpr int kJlaneMaxOwnF64 = 12288;  // fp64 form: 92 us against 97 at 12288, SGPRW ahead at 16384 (profiles/r02_jlane_f64_ab.txt)
 
 }  // namespace
@@ -159,6 +165,28 @@ int reference_order_bodies_per_lane(int own, int cus, int max_b) {
   return best;
 }
 
+// j-splits of the wave-split kernel with the hand-scheduled loop (round 3, profiles/r03_band_sweep.txt).  Round 1's rule -- 32
+// workgroups per CU, i.e. S = 32 up to n = 65536 -- suited the compiler-scheduled loop, which needed eight waves per SIMD to
+// hide its own bubbles.  The hand-scheduled loop is at its rate with two, and every extra split costs a slab write, a slab
+// read by integrate_kernel and a shorter j loop per wave.  The launch lasts as long as the fullest CU: ceil(bi S / CUs)
+// workgroups of 1/S of the j range each.  Take the S (power of two) that minimises that product; among equals the smallest
+// S that still gives every CU two workgroups.  Measured optimum at every size tried: 24576 -> 8 (+2.6 % over S = 32),
+// 32768 -> 4 (+1.9 %), 49152 -> 4 (+1.2 %), 65536 -> 2 (+1.2 %); three workgroups on half the CUs (24576 with S = 4) is 20 % slower.
+int balanced_j_split(int bi, int cus, int max_s) {
+  double best_cost = 0.0;
+  for (int S = 1; S <= max_s; S *= 2) {
+    const double cost = (double)ceil_div(bi * S, cus) / S;
+    if (best_cost == 0.0 || cost < best_cost) best_cost = cost;
+  }
+  int pick = 0, largest = 1;
+  for (int S = 1; S <= max_s; S *= 2) {
+    if ((double)ceil_div(bi * S, cus) / S > best_cost * 1.0001) continue;
+    largest = S;
+    if (!pick && bi * S >= 2 * cus) pick = S;
+  }
+  return pick ? pick : largest;
+}
+
 // Launch shape.  Measured with tools/kbench on MI355X (profiles/r01_kbench_*): the force kernel is
 // VALU-issue bound and wants all 8 wave slots of every SIMD filled, i.e. >= 8192 workgroups of 256
 // threads (32 per CU).  Fastest shape from n = 2k to 1M: j records in SGPRs, the four waves of a
@@ -232,13 +260,18 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   const int iblk = (variant == NBX_KERNEL_SGPRW ? 64 : kBlock) * B;  // bodies per workgroup
   // j-range granularity of one split: a whole LDS tile / two pipelined SGPR batches (per wave)
   // (the hand-scheduled loop of the plain SGPR kernel walks whole trips of up to 64 records)
-  const int gran = variant == NBX_KERNEL_LDS ? kTile : (variant == NBX_KERNEL_SGPR ? 64 : 32);
+  // (round 3: where the balanced split rule applies -- few, long splits -- a split is a whole number of 256-record tiles, so
+  // that every wave's quarter is whole trips of the hand-scheduled loop whatever n is: n = 50000 used to get 32 splits of 1568
+  // records and, with them, the compiler-scheduled loop)
+  const bool balanced = o.j_split <= 0 && c->precision == 32 && variant == NBX_KERNEL_SGPRW && c->i_count > kRound1SplitMaxOwn;
+  const int gran = variant == NBX_KERNEL_LDS ? kTile : (variant == NBX_KERNEL_SGPR ? 64 : (balanced ? 256 : 32));
   static_assert(64 % kSgprAsmTrip<2> == 0 && 64 % kSgprAsmTrip<4> == 0 && kTile % 64 == 0, "j ranges are whole trips of the asm loop");
   const int max_split = std::max(1, c->n_alloc / gran);
   int S = o.j_split;
   if (S <= 0) {
     const int bi = ceil_div(c->i_count, iblk);
-    S = std::min(32, ceil_div(target_wgs, bi));
+    if (balanced) S = balanced_j_split(bi, cus, std::min(32, max_split));
+    else S = std::min(32, ceil_div(target_wgs, bi));
     // the S partial-acceleration slabs are written and re-read every step: keep them <= 256 MiB
     while (S > 1 && (size_t)S * c->own_pad * c->rec > ((size_t)256 << 20)) S /= 2;
   }

@@ -288,6 +288,22 @@ def test_config1_launch_shape_is_frozen(nbx):
                    "fused_epilogue": 0, "force_grid_x": 64, "force_grid_y": 32}, got
 
 
+@pytest.mark.parametrize("n,S,grid_x", [(16384, 32, 64), (14000, 32, 110), (20000, 16, 79), (24576, 8, 96), (32768, 4, 128), (49152, 4, 192),
+                                        (50000, 32, 196), (65536, 2, 256), (98304, 2, 384), (131072, 1, 512)])
+def test_balanced_j_split_rule(nbx, n, S, grid_x):
+    """Round 3: tree-order shapes above 16384 owned bodies take the j-split that loads every CU evenly with
+    the fewest slabs (csrc/nbx_api.hip: balanced_j_split; measured in profiles/r03_band_sweep.txt), in whole 256-record tiles so
+    that the hand-scheduled loop serves every n; up to 16384 the round-1 rule stays (configs[1]'s tree is pinned)."""
+    with nbx.Context(n) as c:
+        st = c.stats()
+    assert st["kernel_variant"] == nbx.KERNEL_SGPRW and st["summation_order"] == nbx.ORDER_TREE and st["bodies_per_lane"] == (4 if n >= 16384 else 2)
+    assert (st["j_split"], st["force_grid_x"], st["force_grid_y"]) == (S if n != 50000 else st["j_split"], grid_x, st["j_split"]), st
+    if n > 16384:
+        assert st["inner_loop"] == nbx.LOOP_ASM  # also for n = 50000, whose 32 splits of 1568 records used to fall back to the compiled loop
+    if n == 50000:
+        assert st["j_split"] == 28  # 32 asked for by the cost model; 28 whole-tile splits of 1792 records cover the 50176 records
+
+
 def test_config1_divergence_curve_beside_the_reference_vs_reference_spread(nbx):
     """configs[1] against TWO builds of the reference's unmodified source -- the pinned -O2 build (the
     oracle) and the -O3 / AVX2 / FMA build (tests/golden/ver7_f32o3_n16384_s500.json).  The north-star gate (1e-4 on the rows
