@@ -42,11 +42,16 @@ enum { NBX_LOOP_AUTO = 0, NBX_LOOP_CXX = 1, NBX_LOOP_ASM = 2, NBX_LOOP_ASM_TS = 
 
 /* kernel_variant values */
 enum {
-  NBX_KERNEL_AUTO = 0,  /* = NBX_KERNEL_SGPRW, the fastest measured on MI355X (profiles/r01_kbench_*) */
+  NBX_KERNEL_AUTO = 0,  /* chosen by size and summation order (csrc/nbx_api.hip: auto_shape): tree order -- NBX_KERNEL_JLANE up to
+                           12288 owned bodies, NBX_KERNEL_SGPRW above; reference order (fp32 runs of n > 131072) -- NBX_KERNEL_SGPR
+                           with one j range and the row epilogue.  nbx_stats reports what was taken */
   NBX_KERNEL_LDS = 1,   /* j-tile (256 records) staged in LDS, broadcast ds_read_b128 (the north-star design) */
   NBX_KERNEL_SGPR = 2,  /* j records fetched by pipelined wave-uniform scalar loads into SGPRs */
   NBX_KERNEL_SGPRW = 3, /* as SGPR, and the 4 waves of a workgroup share 64*B bodies and split the j range */
-  NBX_KERNEL_EXACT = 4, /* validation only (~50x slower): the arithmetic of the reference's pinned build, bit for bit --
+  NBX_KERNEL_EXACT = 4, /* validation only.  Measured cost against the default kernel (profiles/r03_exact_mode_cost.txt): 5.3x at
+                           n = 1048576, 6.5x at 262144, 7.9x at 131072, 14x at 65536, 27x at 32768, 44x at 16384, 72x at 2000 -- one
+                           thread per body is n / 256 workgroups, which fill the 256 CUs only from n = 65536 up.
+                           The arithmetic of the reference's pinned build, bit for bit --
                            one thread per body, j strictly ascending, unfused IEEE multiply/add in the source's
                            association, correctly rounded sqrt and divide, G and m multiplied separately.  Positions
                            and velocities then equal the CPU ver7 run exactly (tests compare CRC-32 of whole arrays) */
