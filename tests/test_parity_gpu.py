@@ -601,7 +601,8 @@ def test_fullsize_tree_sums_are_closer_to_the_true_sum_than_the_reference_arithm
     with nbx.Context(n, summation_order=nbx.ORDER_TREE) as c:
         c.upload(ic)
         ax, ay, az = c.accel()
-        assert c.stats()["summation_order"] == nbx.ORDER_TREE and c.stats()["j_split"] > 1
+        st = c.stats()  # a tree of at least the four wave partials (round 3: one j range per workgroup at this size, four chains per body)
+        assert st["summation_order"] == nbx.ORDER_TREE and (st["j_split"] > 1 or st["kernel_variant"] == nbx.KERNEL_SGPRW)
     with nbx.Context(n, kernel_variant=nbx.KERNEL_EXACT) as c:
         c.upload(ic)
         ex, ey, ez = c.accel()
