@@ -1525,6 +1525,30 @@ def test_rank_whose_peer_left_after_the_rendezvous_ends_with_status_75(tmp_path)
     assert time.time() - t0 < 90
 
 
+def test_two_real_ranks_on_the_one_gpu_get_through_rendezvous_and_rccl_bootstrap(tmp_path):
+    """The farthest two REAL nbody.x processes can go on a 1-GPU box: both draw the particles, rank 0 makes the RCCL token, the
+    TCP rendezvous delivers it, both enter ncclCommInitRank and RCCL's own bootstrap connects them -- and then RCCL refuses the
+    communicator because both ranks sit on device 0 (it has no notion of two ranks sharing a GPU).  What must hold: both processes
+    end promptly with status 1 and RCCL's message (not a hang, not a crash, not the watchdog), and only rank 0 has printed."""
+    import socket
+    import subprocess
+    import time
+    exe = os.path.join(ROOT, "nbody-demo-2023_amd", "host", "nbody.x")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    env = dict(os.environ, NBODY_WORLD="2", NBODY_MASTER_PORT=port, NBODY_DEVICE="0", NBODY_COLLECTIVE_TIMEOUT="60", NBODY_RENDEZVOUS_TIMEOUT="60")
+    t0 = time.time()
+    ps = [subprocess.Popen([exe, "3000", "100"], env=dict(env, NBODY_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    res = [p.communicate(timeout=150) + (p.returncode,) for p in ps]
+    assert time.time() - t0 < 100
+    for r, (out, err, rc) in enumerate(res):
+        assert rc == 1, (r, rc, err[-1500:])
+        assert "nbx_group_create_rank failed" in err and "ncclCommInitRank" in err, (r, err[-1500:])
+        assert ("Initialize Gravity Simulation" in out) == (r == 0)
+
+
 def nbx_exit_collective_timeout():
     return 75  # NBX_EXIT_COLLECTIVE_TIMEOUT (include/nbx.h; tests/test_watchdog.py checks the header)
 
