@@ -42,8 +42,8 @@ enum { NBX_LOOP_AUTO = 0, NBX_LOOP_CXX = 1, NBX_LOOP_ASM = 2, NBX_LOOP_ASM_TS = 
 
 /* kernel_variant values */
 enum {
-  NBX_KERNEL_AUTO = 0,  /* chosen by size and summation order (csrc/nbx_api.hip: auto_shape): tree order -- NBX_KERNEL_JLANE up to
-                           12288 owned bodies, NBX_KERNEL_SGPRW above; reference order (fp32 runs of n > 131072) -- NBX_KERNEL_SGPR
+  NBX_KERNEL_AUTO = 0,  /* chosen by size and summation order (csrc/nbx_api.hip: auto_shape): tree order -- NBX_KERNEL_JLANE below
+                           16384 owned bodies (fp64: up to 12288), NBX_KERNEL_SGPRW from there; reference order (fp32 runs of n > 131072) -- NBX_KERNEL_SGPR
                            with one j range and the row epilogue.  nbx_stats reports what was taken */
   NBX_KERNEL_LDS = 1,   /* j-tile (256 records) staged in LDS, broadcast ds_read_b128 (the north-star design) */
   NBX_KERNEL_SGPR = 2,  /* j records fetched by pipelined wave-uniform scalar loads into SGPRs */
@@ -55,7 +55,7 @@ enum {
                            one thread per body, j strictly ascending, unfused IEEE multiply/add in the source's
                            association, correctly rounded sqrt and divide, G and m multiplied separately.  Positions
                            and velocities then equal the CPU ver7 run exactly (tests compare CRC-32 of whole arrays) */
-  NBX_KERNEL_JLANE = 6, /* tree order, launch-bound sizes (auto up to 12288 owned bodies): a wave owns `bodies_per_lane`
+  NBX_KERNEL_JLANE = 6, /* tree order, launch-bound sizes (auto below 16384 owned bodies; fp64 up to 12288): a wave owns `bodies_per_lane`
                            (2, 4, 8 or, fp32 only, 16) bodies wave-uniformly and its 64 lanes split the j records; lane partials meet in LDS
                            and the wave integrates its bodies itself -- ONE launch per time step, no slabs, no integrate kernel */
   NBX_KERNEL_EXACT_FMA = 5 /* diagnostic: NBX_KERNEL_EXACT with FMA contraction allowed -- what a -march=native / icpc -xAVX2

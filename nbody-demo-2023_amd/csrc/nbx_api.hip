@@ -37,9 +37,12 @@ constexpr int kMaxProfiledLaunches = 8192;
 // reference to 2e-5 in tree order (profiles/r01_validate_orders_n131072_s500.log); 262144 x 200 does not (1.3e-3).
 constexpr int kTreeOrderMaxN = 131072;
 // NBX_KERNEL_AUTO, tree order: contexts that own at most this many bodies step with ONE launch (force_jlane_kernel)
-// (12288: 41 us against SGPRW's 48; at 16384 the two tie at 67 us, and SGPRW's summation tree happens to be the one whose
-// chaotic n = 16384 x 500 run stays inside the 1e-4 gate at every printed step: profiles/r02_config1_by_kernel.txt)
-constexpr int kJlaneMaxOwn = 12288;
+// (12288: 41 us against SGPRW's 48.  Round 3, profiles/r03_band_sweep.txt: between 12288 and 16384 the wave-split kernel falls back
+// to two bodies per lane and, at sizes whose splits are not whole tiles, to the compiled loop -- 40-45 % -- while the one-launch kernel
+// with 8 bodies per wave is 6-15 % ahead: 13000 50.3 vs 53.2 us, 15000 58.0 vs 65.6, 16000 62.8 vs 72.3.)  16384 ITSELF is excluded:
+// there the two tie within 2 %, and SGPRW's summation tree (S = 32) is the one whose chaotic n = 16384 x 500 run -- BASELINE
+// configs[1] -- stays inside the 1e-4 gate at every printed step (profiles/r02_config1_by_kernel.txt, r03_config1_by_shape.txt).
+constexpr int kJlaneMaxOwn = 16383;
 // Tree order, wave-split kernel: contexts that own up to this many bodies keep round 1's split rule (S = 32 at 16384).  Fewer
 // splits are 5 % faster there (profiles/r03_band_sweep.txt: S = 4 or 8), but BASELINE.json configs[1] -- n = 16384 x 500 steps, 450 of
 // them after the bounce -- is decided at the reference's own noise level, and of S = 2, 4, 8, 16, 32 only the tree of S = 32
@@ -238,12 +241,17 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   if (variant == NBX_KERNEL_JLANE || jlane_auto) {
     int NB = o.bodies_per_lane;
     if ((NB != 2 && NB != 4 && NB != 8 && NB != 16) || NB > max_nb) {
-      // A launch lasts as long as the fullest SIMD: ceil(waves / SIMDs) rounds of NB bodies each.  Fewest body-rounds wins;
-      // ties go to the larger NB (fewer waves stream the j records, fewer LDS transposes) -- the measured optimum at every
-      // size from 2048 to 32768 (profiles/r02_jlane_ab.txt: 2048 -> 2, 4096 -> 4, 8192 -> 8, 12288 -> 4, 16384 -> 16).
+      // A launch lasts as long as the fullest SIMD: ceil(waves / SIMDs) rounds of NB bodies each, times what a body-round costs
+      // with that NB.  Measured per body-round and per j record, relative to NB = 8 (profiles/r03_jlane_band.txt: the same ratios
+      // at 12288, 13000 and 16383 bodies): 2 bodies per wave 1.29 (every wave streams all j records and transposes through LDS
+      // for two bodies only), 4 -> 1.06, 8 -> 1.00 (the generated loop), 16 -> 1.06 (compiled loop only).  Smallest product wins:
+      // 2048 -> 2, 4096 -> 4, 8192 -> 8, 12288 -> 4 (three full rounds), 13000 ... 16383 -> 8 -- the measured optimum at each.
+      // Round 2 counted body-rounds alone, which sent 13000 and 14336 to NB = 2 (56.6 us against 50.1 with 8).
+      // fp64 (no generated loop, other ratios not measured): body-rounds alone, ties to the larger NB, as in round 2.
       long best = 0;
       for (int nb = 2; nb <= max_nb; nb *= 2) {
-        const long cost = (long)ceil_div(ceil_div(c->i_count, nb), cus * 4) * nb;
+        const long weight = c->precision != 32 ? 100 : (nb == 2 ? 129 : nb == 8 ? 100 : 106);
+        const long cost = (long)ceil_div(ceil_div(c->i_count, nb), cus * 4) * nb * weight;
         if (best == 0 || cost <= best) { best = cost; NB = nb; }
       }
     }

@@ -203,6 +203,13 @@ def test_jlane_is_the_default_for_launch_bound_sizes_and_shards_like_the_others(
     for n, want in ((2000, nbx.KERNEL_JLANE), (8192, nbx.KERNEL_JLANE), (16384, nbx.KERNEL_SGPRW), (262144, nbx.KERNEL_SGPR)):
         with nbx.Context(n, 32) as c:
             assert c.stats()["kernel_variant"] == want, n
+    # round 3: also between 12288 and 16384 bodies (6-15 % ahead of the two-launch shape there), 8 bodies per wave with the generated
+    # loop; 16384 itself -- BASELINE configs[1] -- keeps the wave-split kernel whose summation tree its fixture was validated with
+    for n, nb in ((12288, 4), (13000, 8), (15000, 8), (16383, 8)):
+        with nbx.Context(n, 32) as c:
+            st = c.stats()
+            assert (st["kernel_variant"], st["bodies_per_lane"]) == (nbx.KERNEL_JLANE, nb), (n, st)
+            assert st["inner_loop"] == (nbx.LOOP_ASM if nb == 8 else st["inner_loop"])
     for n, want in ((2000, nbx.KERNEL_JLANE), (12288, nbx.KERNEL_JLANE), (16384, nbx.KERNEL_SGPRW)):  # fp64 form, same threshold
         with nbx.Context(n, 64) as c:
             assert c.stats()["kernel_variant"] == want, n
@@ -288,7 +295,7 @@ def test_config1_launch_shape_is_frozen(nbx):
                    "fused_epilogue": 0, "force_grid_x": 64, "force_grid_y": 32}, got
 
 
-@pytest.mark.parametrize("n,S,grid_x", [(16384, 32, 64), (14000, 32, 110), (20000, 16, 79), (24576, 8, 96), (32768, 4, 128), (49152, 4, 192),
+@pytest.mark.parametrize("n,S,grid_x", [(16384, 32, 64), (20000, 16, 79), (24576, 8, 96), (32768, 4, 128), (49152, 4, 192),
                                         (50000, 32, 196), (65536, 2, 256), (98304, 2, 384), (131072, 1, 512)])
 def test_balanced_j_split_rule(nbx, n, S, grid_x):
     """Round 3: tree-order shapes above 16384 owned bodies take the j-split that loads every CU evenly with
@@ -296,7 +303,7 @@ def test_balanced_j_split_rule(nbx, n, S, grid_x):
     that the hand-scheduled loop serves every n; up to 16384 the round-1 rule stays (configs[1]'s tree is pinned)."""
     with nbx.Context(n) as c:
         st = c.stats()
-    assert st["kernel_variant"] == nbx.KERNEL_SGPRW and st["summation_order"] == nbx.ORDER_TREE and st["bodies_per_lane"] == (4 if n >= 16384 else 2)
+    assert st["kernel_variant"] == nbx.KERNEL_SGPRW and st["summation_order"] == nbx.ORDER_TREE and st["bodies_per_lane"] == 4
     assert (st["j_split"], st["force_grid_x"], st["force_grid_y"]) == (S if n != 50000 else st["j_split"], grid_x, st["j_split"]), st
     if n > 16384:
         assert st["inner_loop"] == nbx.LOOP_ASM  # also for n = 50000, whose 32 splits of 1568 records used to fall back to the compiled loop
