@@ -116,7 +116,7 @@ def cpu_baseline(kind, n_gpu, precision, build="pinned"):
 
 
 PARITY_FIXTURES = {(262144, 32): "ver7_f32_n262144_s7.json", (16384, 32): "ver7_f32_n16384_s500.json",
-                   (2000, 32): "ver7_f32_n2000_s500.json", (262144, 64): "ver7_f64_n262144_s3.json",
+                   (2000, 32): "ver7_f32_n2000_s500.json", (1000, 32): "ver7_f32_n1000_s100.json", (262144, 64): "ver7_f64_n262144_s3.json",
                    (16384, 64): "ver7_f64_n16384_s60.json", (1048576, 32): "ver7_f32_n1048576_s10.json"}
 
 

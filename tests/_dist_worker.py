@@ -105,6 +105,17 @@ def main():
     res = {"rank": rank, "world": world, "ke": ke, "i_begin": sim.i_begin, "i_count": sim.i_count,
            "block": sim.block, "n_alloc": sim.n_alloc, "bytes_gathered": sim.bytes_gathered,
            "pos_crc": int(np.frombuffer(pos.tobytes(), dtype=np.uint32).sum() & 0xFFFFFFFF)}
+    # bench.py's N > 1 parity leg (collective: every rank calls it): the same sharded simulation restarted from the seed-42
+    # state, 10 steps with the energy all-reduced after each, against the reference's own trace where a fixture exists
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    parity, ke_restart = bench.parity_probe_sharded(sim, {f: getattr(ic, f) for f in ("pos_x", "pos_y", "pos_z", "vel_x", "vel_y", "vel_z", "mass")},
+                                                    n, 32, rank)
+    if rank == 0:
+        with open(out + ".parity", "w") as f:
+            json.dump({"parity": parity, "ke_restart": ke_restart}, f)
     with open("%s.%d" % (out, rank), "w") as f:
         json.dump(res, f)
     np.save("%s.%d.npy" % (out, rank), pos)

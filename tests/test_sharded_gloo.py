@@ -77,6 +77,15 @@ def test_gloo_ranks_reproduce_single_process_trace(oracle, tmp_path, n, world, s
     ag = b["allgather_ms_per_step"]
     assert 0.0 < ag["min"] <= ag["mean"] <= ag["max"] <= b["allgather_ms_worst_step"]
     assert all(r["allgather_ms"] > 0.0 for r in b["per_rank"])
+    # ... and its parity leg: restart from seed 42, 10 steps, energies all-reduced, against the reference's trace
+    par = json.load(open(out + ".parity"))
+    assert par["ke_restart"] == res[0]["ke"][:10]  # the restart reproduces the first run, bit for bit
+    if n == 1000:  # a fixture from the reference's own binary exists for this size
+        p = par["parity"]
+        assert p["fixture"] == "ver7_f32_n1000_s100.json" and p["steps"] == 10 and p["ranks"] == world
+        assert p["pass"] and p["max_rel_kenergy_err"] < 2e-6 and len(p["rel_kenergy_err_per_step"]) == 10
+    else:
+        assert par["parity"] is None
 
 
 def test_rank_report_summary_arithmetic():

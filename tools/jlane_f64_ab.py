@@ -2,11 +2,11 @@
 import sys, time
 sys.path.insert(0, 'nbody-demo-2023_amd')
 import nbx
-for n in (2000, 2048, 4096, 8192, 12288, 16384):
+for n in ([int(x) for x in sys.argv[1:]] or [2000, 2048, 4096, 8192, 12288, 16384]):
     ic = nbx.initial_conditions(n, 64)
     row, ref = [], None
     for name, kw in (("sgprw", dict(kernel_variant=nbx.KERNEL_SGPRW)), ("jlane2", dict(kernel_variant=nbx.KERNEL_JLANE, bodies_per_lane=2)),
-                     ("jlane4", dict(kernel_variant=nbx.KERNEL_JLANE, bodies_per_lane=4)), ("jlane8", dict(kernel_variant=nbx.KERNEL_JLANE, bodies_per_lane=8))):
+                     ("jlane4", dict(kernel_variant=nbx.KERNEL_JLANE, bodies_per_lane=4)), ("jlane8", dict(kernel_variant=nbx.KERNEL_JLANE, bodies_per_lane=8)), ("auto", dict())):
         with nbx.Context(n, 64, **kw) as c:
             c.upload(ic)
             ke = c.step(20)
