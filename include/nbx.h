@@ -247,7 +247,9 @@ int nbx_group_create_rank(nbx_group** out, int32_t n, int32_t precision, int32_t
  * in ncclCommInitRank or in the stream synchronisation behind an all-gather without error.  libnbx watches those calls
  * -- ncclCommInitRank in nbx_group_create_rank, the synchronisation of nbx_group_step when kenergy_out != NULL,
  * nbx_group_download, nbx_group_destroy -- from a host thread: when one of them has not returned `seconds` after it
- * should have (the limit is `seconds` plus four times the measured duration of the steps still queued in front of it),
+ * should have (the limit is `seconds` plus four times the measured duration of the steps still queued in front of it; for
+ * ncclCommInitRank `seconds` plus 30 -- NBX_RCCL_INIT_ALLOWANCE in the environment -- for RCCL's own set-up, which takes
+ * 4-5 s even for a world of one),
  * the thread writes which call is stuck on which rank to stderr and ends the process with
  * _exit(NBX_EXIT_COLLECTIVE_TIMEOUT): a collective cannot be abandoned from inside the process, so the bound is on the
  * process; there is no re-exec and no retry.  Process-wide.  Default: the environment's NBX_COLLECTIVE_TIMEOUT, else 120;

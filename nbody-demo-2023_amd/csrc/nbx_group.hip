@@ -23,6 +23,7 @@
 using namespace nbx_detail;
 
 namespace {
+constexpr double kRcclInitAllowanceSeconds = 30.0;  // added to the collective timeout for ncclCommInitRank (see there)
 constexpr int kTile = 256;  // records per block alignment (= nbx::kTile: j tile of the kernels; checked in nbx_api.hip)
 }  // namespace
 
@@ -310,7 +311,11 @@ int nbx_group_create_rank(nbx_group** out, int32_t n, int32_t precision, int32_t
   Watchdog::instance().set_identity(rank, P);
   ncclResult_t e;
   {
-    Watchdog::Scope bounded("ncclCommInitRank (nbx_group_create_rank)");  // blocks until all P ranks have called it
+    // blocks until all P ranks have called it.  RCCL's own set-up -- loading its kernels, topology detection, channel set-up --
+    // is legitimate work in front of the hand-shake: 4-5 s for a world of one on a cold process (measured), more on eight GPUs
+    double init_allowance = kRcclInitAllowanceSeconds;  // NBX_RCCL_INIT_ALLOWANCE=<seconds> overrides (large nodes; tests)
+    if (const char* e = std::getenv("NBX_RCCL_INIT_ALLOWANCE")) { char* end = nullptr; const double v = std::strtod(e, &end); if (end != e && v >= 0.0) init_allowance = v; }
+    Watchdog::Scope bounded("ncclCommInitRank (nbx_group_create_rank)", init_allowance);
     e = g_rccl.CommInitRank(&g->comm[0], P, id, rank);
   }
   if (e != ncclSuccess) { g->comm.clear(); return rccl_fail("ncclCommInitRank", e); }
