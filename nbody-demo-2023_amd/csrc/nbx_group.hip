@@ -314,7 +314,11 @@ int nbx_group_create_rank(nbx_group** out, int32_t n, int32_t precision, int32_t
     // blocks until all P ranks have called it.  RCCL's own set-up -- loading its kernels, topology detection, channel set-up --
     // is legitimate work in front of the hand-shake: 4-5 s for a world of one on a cold process (measured), more on eight GPUs
     double init_allowance = kRcclInitAllowanceSeconds;  // NBX_RCCL_INIT_ALLOWANCE=<seconds> overrides (large nodes; tests)
-    if (const char* e = std::getenv("NBX_RCCL_INIT_ALLOWANCE")) { char* end = nullptr; const double v = std::strtod(e, &end); if (end != e && v >= 0.0) init_allowance = v; }
+    if (const char* txt = std::getenv("NBX_RCCL_INIT_ALLOWANCE")) {
+      char* end = nullptr;
+      const double v = std::strtod(txt, &end);
+      if (end != txt && v >= 0.0) init_allowance = v;
+    }
     Watchdog::Scope bounded("ncclCommInitRank (nbx_group_create_rank)", init_allowance);
     e = g_rccl.CommInitRank(&g->comm[0], P, id, rank);
   }
