@@ -227,11 +227,12 @@ def native_rank_group_check(dist, rank, world, device, n, precision, ke_torch_pa
     res = {"rank": rank, "returncode": None}
     with tempfile.TemporaryDirectory() as td:
         jpath = os.path.join(td, "native.json")
-        env = dict(os.environ, NBODY_WORLD=str(world), NBODY_RANK=str(rank), NBODY_LOCAL_RANK=str(device), NBODY_MASTER_ADDR="127.0.0.1",
+        # the child runs the drop-in's DEFAULTS: no knob of the caller's shell leaks into it (NBODY_DEVICE would put every rank
+        # on one GPU, NBODY_KERNEL / NBODY_ORDER would change what is compared)
+        env = {k: v for k, v in os.environ.items() if not k.startswith("NBODY_") and k not in ("NBX_EXCHANGE", "NBX_SLICE_BIT")}
+        env.update(NBODY_WORLD=str(world), NBODY_RANK=str(rank), NBODY_LOCAL_RANK=str(device), NBODY_MASTER_ADDR="127.0.0.1",
                    NBODY_MASTER_PORT=str(port[0]), NBODY_SFREQ=str(window), NBODY_JSON=jpath, NBODY_COLLECTIVE_TIMEOUT="60",
                    NBODY_RENDEZVOUS_TIMEOUT="60")
-        for k in ("NBODY_GPUS", "NBX_EXCHANGE", "NBODY_KERNEL", "NBODY_ORDER", "NBODY_JSPLIT", "NBODY_BPL"):
-            env.pop(k, None)
         t0 = time.perf_counter()
         try:
             p = subprocess.run([exe, str(n), str(2 * window)], env=env, capture_output=True, text=True, timeout=420)
