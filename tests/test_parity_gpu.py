@@ -1600,18 +1600,18 @@ def test_two_real_ranks_on_the_one_gpu_get_through_rendezvous_and_rccl_bootstrap
 
 
 def test_watchdog_does_not_mistake_a_long_window_for_a_dead_peer(tmp_path):
-    """The bound is on the collective, not on the work queued in front of it: with a 4 s timeout (ncclCommInitRank itself needs a
-    second or two), print windows of ~12 s (n = 1048576, 50 steps of ~235 ms) must run to the end -- the deadline is the timeout
-    plus the window's expected duration (a conservative rate before the first window has been timed, four times the measured step
-    time afterwards)."""
+    """The bound is on the collective, not on the work queued in front of it: with a 3 s timeout, print windows of ~6 s
+    (n = 1048576, 25 steps of ~235 ms) must run to the end -- the deadline is the timeout plus the window's expected duration
+    (a conservative rate before the first window has been timed, four times the measured step time afterwards; ncclCommInitRank
+    has its own allowance for RCCL's set-up)."""
     import subprocess
     exe = os.path.join(ROOT, "nbody-demo-2023_amd", "host", "nbody.x")
     out = str(tmp_path / "w.json")
-    p = subprocess.run([exe, "1048576", "100"], env=dict(os.environ, NBODY_WORLD="1", NBODY_RANK="0", NBODY_COLLECTIVE_TIMEOUT="4", NBODY_JSON=out),
-                       capture_output=True, text=True, timeout=400)
+    p = subprocess.run([exe, "1048576", "50"], env=dict(os.environ, NBODY_WORLD="1", NBODY_RANK="0", NBODY_COLLECTIVE_TIMEOUT="3", NBODY_SFREQ="25",
+                                                        NBODY_JSON=out), capture_output=True, text=True, timeout=400)
     assert p.returncode == 0, (p.returncode, p.stderr[-1500:])
     w = json.load(open(out))["windows"]
-    assert [x["step"] for x in w] == [50, 100] and all(x["seconds"] > 6.0 for x in w)  # each window outlasts the bare timeout
+    assert [x["step"] for x in w] == [25, 50] and all(x["seconds"] > 4.5 for x in w)  # each window outlasts the bare timeout
 
 
 def nbx_exit_collective_timeout():
