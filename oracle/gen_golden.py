@@ -30,7 +30,8 @@ CASES = [
     ("f32", 4099, 40),      # n not a multiple of any tile
     ("f32", 4096, 200),     # sizes the one-launch jlane kernel serves by default (round 2): NB = 2 ...
     ("f32", 8192, 200),     # ... NB = 4 ...
-    ("f32", 12288, 100),    # ... and the largest one, NB = 8
+    ("f32", 12288, 100),    # ... and the largest one of round 2, NB = 4
+    ("f32", 15000, 100),    # round 3: the one-launch kernel's range now ends at 16383 (NB = 8)
     ("f32", 16384, 500),    # BASELINE.json configs[1]
     ("f32", 65536, 20),
     ("f64", 5, 20),

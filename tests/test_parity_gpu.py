@@ -124,7 +124,7 @@ def test_jlane_fp64_traces_against_the_reference_fp64_build(nbx, name):
         assert abs(t.step(steps) / ke[-1] - 1.0) < 1e-12     # the two-launch tree shape: another tree, same answer
 
 
-@pytest.mark.parametrize("n,steps,NB", [(2000, 500, 0), (4099, 40, 0), (1000, 100, 16), (65, 20, 4), (5, 20, 2), (8192, 30, 0)])
+@pytest.mark.parametrize("n,steps,NB", [(2000, 500, 0), (4099, 40, 0), (1000, 100, 16), (65, 20, 4), (5, 20, 2), (8192, 30, 0), (15000, 100, 0)])
 def test_jlane_trajectory_matches_the_two_launch_tree_shape_and_the_reference(nbx, n, steps, NB):
     """force + Euler + energy in one launch: kinetic energy within rounding of the SGPRW + integrate_kernel pair at every step,
     against the reference's fixture where one exists, bitwise reproducible, and identical under hipGraph replay."""
@@ -152,7 +152,7 @@ def test_jlane_trajectory_matches_the_two_launch_tree_shape_and_the_reference(nb
         assert np.array_equal(fin[f], fin2[f]), f
 
 
-@pytest.mark.parametrize("name", ["ver7_f32_n4096_s200.json", "ver7_f32_n8192_s200.json", "ver7_f32_n12288_s100.json"])
+@pytest.mark.parametrize("name", ["ver7_f32_n4096_s200.json", "ver7_f32_n8192_s200.json", "ver7_f32_n12288_s100.json", "ver7_f32_n15000_s100.json"])
 def test_jlane_sizes_against_the_reference_binary(nbx, name):
     """The sizes the one-launch kernel serves by default (NB = 2, 4, 8) against fixtures produced by the reference's own
     ver7 binary: kinetic energy at every printed step (s % 50 == 0) within the north-star gate of 1e-4, and the exact mode
@@ -178,7 +178,7 @@ def test_jlane_sizes_against_the_reference_binary(nbx, name):
 
 
 @pytest.mark.parametrize("NB", [2, 4, 8])
-@pytest.mark.parametrize("n,steps", [(5, 10), (300, 30), (2000, 40), (2048, 20), (4099, 20), (8192, 10), (12288, 6), (768, 25)])
+@pytest.mark.parametrize("n,steps", [(5, 10), (300, 30), (2000, 40), (2048, 20), (4099, 20), (8192, 10), (12288, 6), (768, 25), (15000, 5), (16383, 4)])
 def test_jlane_hand_scheduled_main_loop_is_bit_equal_to_the_compiled_one(nbx, n, steps, NB):
     """Whole trips of 8 records per lane through the generated loop (nbx_jlane_loop.inc), the remainder through the compiled
     one: same bits as the all-compiled kernel -- sizes with 0 trips (n <= 256), with and without a 4-record remainder."""
