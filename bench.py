@@ -14,9 +14,16 @@ all-gather of the positions per step).  Prints ONE JSON line on rank 0.
 
 An N > 1 line validates itself (all outside the timed region): `parity` = the same sharded simulation restarted
 from the seed-42 state, 10 steps against the reference's own trace; `ranks` = force-kernel and all-gather times
-of every rank (min / mean / max, skew, bytes, devices); `native_rank_group` = the drop-in's own multi-process
-path (nbody.x per rank: TCP rendezvous, ncclCommInitRank, in-place ncclAllGather inside libnbx) run on the same
-GPUs and compared with the torch.distributed path.
+of every rank (min / mean / max, skew, bytes, devices); and the PRODUCT's own two multi-GPU forms run on the same
+GPUs, timed and compared with the torch.distributed figure: `native_single_process` = one nbody.x driving all N
+GPUs from one host thread (NBODY_GPUS=N: nbx_group_create -> ncclCommInitAll -> grouped in-place ncclAllGather per
+step; `value_native_single_process`), `native_rank_group` = nbody.x per rank (TCP rendezvous, ncclCommInitRank,
+in-place ncclAllGather inside libnbx; `value_native_rank_group`).  The N > 1 line also carries both denominators of
+a scaling record: `cpu_baseline` (rank 0, before it touches the GPU) and `one_gpu_at_multi_gpu_n` (rank 0's GPU
+alone at the same n, the other ranks idle at a barrier).
+
+An N = 1 line carries `multi_gpu_slice_proxy`: what ONE rank of 2 / 4 / 8 computes per step at n = 262144, 524288 and
+1048576 on this one GPU, next to the one-GPU step at the same n: the multi-GPU speed-up before communication and skew.
 """
 import argparse
 import json
@@ -221,6 +228,11 @@ def native_rank_group_check(dist, rank, world, device, n, precision, ke_torch_pa
     A child per rank rather than an in-process group: whatever happens in there (an RCCL refusal, the collective watchdog
     ending a stuck rank with status 75) ends the CHILD; this process goes on and prints its line.  Two windows of `window`
     steps: the first carries RCCL's lazy channel set-up, the second is the timing.  Collective: every rank calls it."""
+    hosts = [None] * world
+    dist.all_gather_object(hosts, socket.gethostname())
+    if len(set(hosts)) > 1:
+        # the children rendezvous on 127.0.0.1: ranks on other nodes would wait out NBODY_RENDEZVOUS_TIMEOUT for nothing
+        return {"skipped": "ranks on %d hosts: this leg starts its children on one node only" % len(set(hosts))} if rank == 0 else None
     port = [_free_port() if rank == 0 else None]
     dist.broadcast_object_list(port, src=0)
     exe = os.path.join(PKG, "host", "nbody.x" if precision == 32 else "nbody_fp64.x")
@@ -274,10 +286,107 @@ def native_rank_group_check(dist, rank, world, device, n, precision, ke_torch_pa
     return out
 
 
+def time_one_gpu(nbx, sharded, n, precision, opts, steps=3):
+    """A few whole steps of ONE context that owns all n bodies (the denominator of every multi-GPU speed-up at this n)."""
+    big = sharded.ShardedSimulation(n, precision, dist=None, **opts)
+    big.upload(nbx.initial_conditions(n, precision))
+    big.step(1)
+    big.sync()
+    tb = time.perf_counter()
+    big.step(steps)
+    big.sync()
+    t = (time.perf_counter() - tb) / steps
+    big.close()
+    return t
+
+
+def slice_proxy_cell(nbx, n, P, precision, opts, ic, t_one_gpu, budget_s=0.25):
+    """What ONE rank of P computes per step at n bodies -- rank 0's block of the library's partition (nbx_partition) against all
+    n_alloc resident records -- timed on this one GPU: the P-GPU step before communication and skew.  NOT a P-GPU measurement."""
+    used, block, i_begin, i_count, n_alloc = nbx.partition(n, P, 0)
+    with nbx.Context(n, precision, i_begin=i_begin, i_count=i_count, n_alloc=n_alloc, **opts) as c:
+        c.upload(ic)
+        for _ in range(2):
+            c.step_local(); c.commit()
+        c.sync()
+        tb = time.perf_counter()
+        c.step_local(); c.commit()
+        c.sync()
+        reps = max(3, min(50, int(budget_s / max(time.perf_counter() - tb, 1e-5))))
+        c.profile(True)
+        tb = time.perf_counter()
+        for _ in range(reps):
+            c.step_local(); c.commit()
+        c.sync()
+        t_rank = (time.perf_counter() - tb) / reps
+        st = c.stats()
+    peak = (PEAK_FP32_VECTOR_TFLOPS if precision == 32 else PEAK_FP64_VECTOR_TFLOPS) * 1e12
+    return {"n_bodies": n, "gpus": P, "measured": False, "bodies_owned": i_count, "steps": reps, "ms_per_step": 1e3 * t_rank,
+            "force_kernel_ms": st["force_ms_total"] / max(1, st["force_launches_timed"]),
+            "roofline_frac": FLOP_PER_PAIR * float(i_count) * float(n) / t_rank / peak,
+            "bodies_per_lane": st["bodies_per_lane"], "grid": [st["force_grid_x"], st["force_grid_y"]],
+            "kernel": {1: "lds", 2: "sgpr", 3: "sgprw", 6: "jlane"}.get(st["kernel_variant"], "?"), "inner_loop": LOOP_NAMES.get(st["inner_loop"], "?"),
+            "one_gpu_ms_per_step": 1e3 * t_one_gpu,
+            "implied_%dgpu_speedup_before_communication" % P: t_one_gpu / t_rank,
+            "note": "measured on ONE GPU with a %d-body slice; not a %d-GPU measurement" % (i_count, P)}
+
+
+def native_single_process_check(dist, rank, world, n, precision, ke_torch_path, window=10):
+    """The product's single-process multi-GPU form -- the design SURVEY.md section 5 specified -- on the GPUs of this job: rank 0
+    alone starts ONE `nbody.x` with NBODY_GPUS=<world> (one host thread, a context and a stream per GPU: nbx_group_create ->
+    ncclCommInitAll -> per step every rank's local step, then one grouped in-place ncclAllGather: csrc/nbx_group.hip), the other
+    ranks idle at the gather below.  Replaces mpi_bcast_all + mpi_gather_acc of ver5_all/GSimulation.cpp:170-214 without any
+    second process.  A child, so that an RCCL refusal or the collective watchdog ends the child and not this line.  Two windows of
+    `window` steps: the first carries RCCL's lazy channel set-up, the second is the timing.  With a world of one the child is told
+    NBX_EXCHANGE=rccl: a one-device communicator, every collective of the path with one participant (1-GPU rehearsal).
+    Collective: every rank calls it."""
+    exe = os.path.join(PKG, "host", "nbody.x" if precision == 32 else "nbody_fp64.x")
+    res = None
+    if rank == 0:
+        res = {"binary": os.path.relpath(exe, ROOT), "gpus": world, "steps": 2 * window,
+               "path": "NBODY_GPUS=%d: one process, one host thread -> nbx_group_create (ncclCommInitAll) -> nbx_group_step: local steps + one grouped in-place "
+                       "ncclAllGather per step (csrc/nbx_group.hip)" % world}
+        with tempfile.TemporaryDirectory() as td:
+            jpath = os.path.join(td, "single.json")
+            env = {k: v for k, v in os.environ.items() if not k.startswith("NBODY_") and k not in ("NBX_EXCHANGE", "NBX_SLICE_BIT", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+            env.update(NBODY_GPUS=str(world), NBODY_SFREQ=str(window), NBODY_JSON=jpath, NBODY_COLLECTIVE_TIMEOUT="60")
+            if world == 1:
+                env["NBX_EXCHANGE"] = "rccl"
+            t0 = time.perf_counter()
+            try:
+                p = subprocess.run([exe, str(n), str(2 * window)], env=env, capture_output=True, text=True, timeout=420)
+                res["returncode"] = p.returncode
+                if p.returncode != 0:
+                    res["error"] = p.stderr[-400:] or "status %r" % p.returncode
+                else:
+                    j = json.load(open(jpath))
+                    w = j["windows"]
+                    res.update({"exchange": j["exchange"], "uses_rccl": j["uses_rccl"], "ranks": j["ranks"], "one_process_per_rank": j["one_process_per_rank"],
+                                "ms_per_step": 1e3 * w[1]["seconds"] / window, "ms_per_step_first_window": 1e3 * w[0]["seconds"] / window,
+                                "pair_per_s": float(n) * n * window / w[1]["seconds"], "kenergy_step%d" % window: w[0]["kenergy"],
+                                "bodies_per_lane": j["bodies_per_lane"], "grid": j["grid"]})
+                    if ke_torch_path is not None:
+                        d = abs(w[0]["kenergy"] - ke_torch_path) / abs(ke_torch_path)
+                        res["rel_diff_vs_torch_path"] = d
+                        res["kenergy_equal_to_torch_path"] = bool(d < 1e-12)
+                    name, g = parity_fixture(n, precision)
+                    if g and g["nsteps"] >= window:
+                        res["rel_kenergy_err_vs_reference_step%d" % window] = abs(w[0]["kenergy"] - g["kenergy"][window - 1]) / g["kenergy"][window - 1]
+            except Exception as e:  # reported, never raised
+                res["error"] = "%s: %s" % (type(e).__name__, e)
+            res["wall_s"] = time.perf_counter() - t0
+    box = [res]
+    dist.broadcast_object_list(box, src=0)  # the other ranks wait here, their GPUs idle, until rank 0's child has finished
+    return box[0] if rank == 0 else None
+
+
+LOOP_NAMES = {1: "cxx", 2: "asm", 3: "asm_ts", 4: "asm_pf"}
+
+
 def ran_shape(st):
     """The launch shape in the vocabulary of profiles/roofline_traffic.json's `profiled_shape` (tools/roofline_summary.py)."""
     return {"bodies_per_lane": st["bodies_per_lane"], "epilogue": "row" if st["fused_epilogue"] == 1 else "slab", "j_split": st["j_split"],
-            "wave_split": st["kernel_variant"] == 3, "loop": {1: "cxx", 2: "asm", 3: "asm_ts"}.get(st["inner_loop"], "?")}
+            "wave_split": st["kernel_variant"] == 3, "loop": LOOP_NAMES.get(st["inner_loop"], "?")}
 
 
 def main():
@@ -317,7 +426,7 @@ def main():
 
     # CPU baseline first: it may start a child process, so it runs before this process touches the GPU
     cpu = cpu_o3 = None
-    if a.gpus == 1 and rank == 0 and a.cpu_baseline != "none":
+    if rank == 0 and a.cpu_baseline != "none":  # N > 1 too: a scaling record then carries its own CPU denominator
         cpu = cpu_baseline(a.cpu_baseline, n, a.precision)
         # SURVEY.md 8d asks for both builds of the reference: the pinned -O2 one above (the oracle's flags) and a best-effort one
         if cpu["kind"] == "reference" and a.precision == 32 and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ver7_trace_o3.x")):
@@ -359,8 +468,6 @@ def main():
     sim.step(a.warmup)
     fence()
     sim.engine.ctx.profile(True)  # HIP events around every force launch, on the context's own stream
-    if use_dist:
-        sim.profile_exchange(True)  # and around every all-gather (events on the same stream over RCCL)
     t0 = time.perf_counter()
     sim.step(a.steps)
     fence()
@@ -374,8 +481,15 @@ def main():
     ke = sim.kenergy()
 
     # N > 1: what every rank did, gathered to rank 0 -- a sub-6x result must be diagnosable from the line alone
-    breakdown = native = None
+    breakdown = native = native_single = same_n_multi = None
     if use_dist:
+        # the all-gathers are timed in a pass of their own, AFTER the timed region (two event records per step inside
+        # the headline's clock were small but unmeasured): the same number of steps, events on the stream the kernel and the
+        # collective are ordered on
+        sim.engine.ctx.profile(False)
+        sim.profile_exchange(True)
+        sim.step(a.steps)
+        fence()
         xms = sim.exchange_ms()
         sim.profile_exchange(False)
         report = {"rank": rank, "device": torch.cuda.current_device(), "host": socket.gethostname(), "bodies_owned": st["i_count"],
@@ -393,6 +507,18 @@ def main():
                                              ke_trace[9] if len(ke_trace) >= 10 else None)
         elif rank == 0:
             native = {"skipped": "rehearsal backend %s: RCCL refuses several ranks on one device" % dist.get_backend()}
+        # the product's single-process form over all the job's GPUs (rank 0 starts it, the others idle), and rank 0's GPU alone
+        # at the same n: the denominator of this line's speed-up, measured in the same run
+        if dist.get_backend() == "nccl" and not os.environ.get("NBX_BENCH_NO_NATIVE"):
+            native_single = native_single_process_check(dist, rank, dist.get_world_size(), n, a.precision,
+                                                        ke_trace[9] if len(ke_trace) >= 10 else None)
+        elif rank == 0:
+            native_single = {"skipped": "rehearsal backend %s: the ranks share one device" % dist.get_backend()}
+        if rank == 0 and not os.environ.get("NBX_BENCH_NO_ONE_GPU"):
+            t_one = time_one_gpu(nbx, sharded, n, a.precision, opts, steps=3 if n >= 524288 else 10)
+            same_n_multi = {"n_bodies": n, "steps": 3 if n >= 524288 else 10, "value": float(n) * n / t_one, "unit": "pair/s", "ms_per_step": 1e3 * t_one,
+                            "device": torch.cuda.current_device(), "note": "rank 0's GPU alone, all n bodies in one context, the other ranks idle"}
+        dist.barrier()
 
     # N == 1 only: the multi-GPU runs use configs[3]'s n = 1048576; time a few steps of it on this one GPU as
     # well, so that scaling can also be read at equal n (pair/s is nearly flat in n here, see profiles/r01_sweep_*)
@@ -418,44 +544,27 @@ def main():
                        "kernel": {1: "lds", 2: "sgpr", 3: "sgprw", 6: "jlane"}.get(st2["kernel_variant"], "?"), "bodies_per_lane": st2["bodies_per_lane"],
                        "j_split": st2["j_split"]}
         s2.close()
+    proxy = None
     if world == 1 and not a.n and a.precision == 32:
-        big = sharded.ShardedSimulation(1048576, 32, dist=None, **opts)
-        big.upload(nbx.initial_conditions(1048576, 32))
-        big.step(1)
-        big.sync()
-        tb = time.perf_counter()
-        big.step(3)
-        big.sync()
-        t_big = (time.perf_counter() - tb) / 3.0
+        # What ONE rank of the 2-, 4- and 8-GPU forms computes per step at n = 262144, 524288 and 1048576 (configs[3]) -- its block of the
+        # partition against all resident records -- on this GPU, next to one GPU stepping all n bodies: the P-GPU speed-up over one GPU at
+        # the same n, before communication and skew, is the ratio of the two (at n = 1M, P = 8 the all-gather is 2 MiB sent / 14 MiB
+        # received per rank and step).  Reference order gives one chain per owned body, so small slices leave SIMDs idle: these are the
+        # cells a multi-GPU table will show, reported here so that no scaling record is needed to see them.
+        t_same = {262144: elapsed / a.steps}
+        cells = []
+        for nn in (262144, 524288, 1048576):
+            if nn not in t_same:
+                t_same[nn] = time_one_gpu(nbx, sharded, nn, 32, opts, steps=3)
+            ic_nn = ic if nn == n else nbx.initial_conditions(nn, 32)
+            for P in (2, 4, 8):
+                cells.append(slice_proxy_cell(nbx, nn, P, 32, opts, ic_nn, t_same[nn]))
+        t_big = t_same[1048576]
         same_n = {"n_bodies": 1048576, "steps": 3, "value": 1048576.0 ** 2 / t_big, "unit": "pair/s", "ms_per_step": 1e3 * t_big}
-        big.close()
-        # what ONE rank of the 8-, 4- and 2-GPU forms of configs[3] computes per step: 131072 / 262144 / 524288 owned bodies against
-        # all 1048576 resident records, on this GPU.  The P-GPU speed-up over one GPU at the same n, before communication and skew,
-        # is the ratio of the two step times (at P = 8 the all-gather is 2 MiB sent / 14 MiB received per rank and step).
-        ic_big = nbx.initial_conditions(1048576, 32)
-        ranks = []
-        for P, reps in ((8, 6), (4, 4), (2, 3)):
-            own = 1048576 // P
-            with nbx.Context(1048576, 32, i_begin=0, i_count=own, n_alloc=1048576, **opts) as cP:
-                cP.upload(ic_big)
-                for _ in range(2):
-                    cP.step_local(); cP.commit()
-                cP.sync()
-                cP.profile(True)
-                tb = time.perf_counter()
-                for _ in range(reps):
-                    cP.step_local(); cP.commit()
-                cP.sync()
-                t_rank = (time.perf_counter() - tb) / reps
-                stP = cP.stats()
-            ranks.append({"n_bodies": 1048576, "bodies_owned": own, "steps": reps, "ms_per_step": 1e3 * t_rank,
-                          "force_kernel_ms": stP["force_ms_total"] / max(1, stP["force_launches_timed"]),
-                          "roofline_frac": FLOP_PER_PAIR * float(own) * 1048576.0 / t_rank / (PEAK_FP32_VECTOR_TFLOPS * 1e12),
-                          "bodies_per_lane": stP["bodies_per_lane"], "grid": [stP["force_grid_x"], stP["force_grid_y"]],
-                          "inner_loop": {1: "cxx", 2: "asm", 3: "asm_ts"}.get(stP["inner_loop"], "?"),
-                          "implied_%dgpu_speedup_before_communication" % P: t_big / t_rank,
-                          "note": "measured on ONE GPU with a %d-body slice; not a %d-GPU measurement" % (own, P)})
-        rank8, rank4, rank2 = ranks
+        proxy = {"what": "one rank's block of n bodies on P GPUs, timed on ONE GPU (plain launches, no exchange); speed-up = one GPU at the same n / that",
+                 "one_gpu_ms_per_step": {str(k): 1e3 * v for k, v in t_same.items()}, "cells": cells}
+        by = {(c["n_bodies"], c["gpus"]): c for c in cells}
+        rank8, rank4, rank2 = by[(1048576, 8)], by[(1048576, 4)], by[(1048576, 2)]
 
     if rank == 0:
         pairs_per_step = float(n) * float(n)
@@ -505,7 +614,8 @@ def main():
                        "bodies_per_lane": st["bodies_per_lane"], "j_split": st["j_split"],
                        "summation_order": {1: "reference", 2: "tree"}.get(st["summation_order"], "?"),
                        "kernel": {1: "lds", 2: "sgpr", 3: "sgprw", 4: "exact", 6: "jlane"}.get(st["kernel_variant"], "?"),
-                       "inner_loop": {1: "compiler-scheduled", 2: "hand-scheduled asm", 3: "hand-scheduled asm, time-sliced wave priority"}.get(st["inner_loop"], "?"),
+                       "inner_loop": {1: "compiler-scheduled", 2: "hand-scheduled asm" + (", two j records per packed operation" if st["bodies_per_lane"] == 1 and st["kernel_variant"] == 2 else ""),
+                                      3: "hand-scheduled asm, time-sliced wave priority", 4: "hand-scheduled asm, L2 prefetch"}.get(st["inner_loop"], "?"),
                        "grid": [st["force_grid_x"], st["force_grid_y"]], "block": st["force_block"]},
             "gflops_reference_convention": 1e-9 * (29.0 * pairs_per_step + 19.0 * n) * a.steps / elapsed,
             "kenergy_after_run": ke,
@@ -536,6 +646,19 @@ def main():
             line["native_rank_group"] = native
         if same_n:
             line["one_gpu_at_multi_gpu_n"] = same_n
+        if same_n_multi:
+            line["one_gpu_at_multi_gpu_n"] = same_n_multi
+            line["speedup_vs_one_gpu_same_n"] = same_n_multi["ms_per_step"] / (1e3 * elapsed / a.steps)
+        if use_dist:
+            # the three ways this job can be run, side by side: torch.distributed driving libnbx (the timed region above), the product's
+            # single-process group (one host thread, all GPUs) and the product's one-process-per-GPU group
+            line["value_torch_distributed"] = value
+            line["value_native_single_process"] = (native_single or {}).get("pair_per_s")
+            line["value_native_rank_group"] = (native or {}).get("pair_per_s")
+        if native_single:
+            line["native_single_process"] = native_single
+        if proxy:
+            line["multi_gpu_slice_proxy"] = proxy
         if rank8:
             line["one_rank_of_8_at_1m"] = rank8
             line["one_rank_of_4_at_1m"] = rank4

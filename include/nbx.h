@@ -38,7 +38,7 @@ enum {
 };
 
 enum { NBX_ORDER_AUTO = 0, NBX_ORDER_REFERENCE = 1, NBX_ORDER_TREE = 2 };
-enum { NBX_LOOP_AUTO = 0, NBX_LOOP_CXX = 1, NBX_LOOP_ASM = 2, NBX_LOOP_ASM_TS = 3 };
+enum { NBX_LOOP_AUTO = 0, NBX_LOOP_CXX = 1, NBX_LOOP_ASM = 2, NBX_LOOP_ASM_TS = 3, NBX_LOOP_ASM_PF = 4 };
 
 /* kernel_variant values */
 enum {

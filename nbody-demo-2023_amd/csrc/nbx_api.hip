@@ -72,6 +72,10 @@ using ForceLauncher = void (*)(const ForceArgs<T>&, dim3, hipStream_t);
 
 template <typename T, int JSRC, int EPI, int MATH, bool WS>
 ForceLauncher<T> pick_b(int B, int loop) {
+  if constexpr (sizeof(T) == 4 && JSRC == JSRC_SGPR && MATH == MATH_SCALAR && !WS) {
+    // one body per lane: the hand-scheduled loop is the two-j-records-per-operation one (sgpr_loop_asm_jpair)
+    if (B == 1 && loop != LOOP_CXX) return launch_force_t<T, 1, JSRC, EPI, MATH, WS, LOOP_ASM>;
+  }
   if constexpr (kHasAsmLoop<T, JSRC, EPI, MATH, WS>) {
     if constexpr (!WS && EPI == EPI_ROW) {  // time-sliced priority: the whole-launch-resident reference-order shapes only
       if (loop == LOOP_ASM_TS) {
@@ -79,8 +83,13 @@ ForceLauncher<T> pick_b(int B, int loop) {
         if (B == 4) return launch_force_t<T, 4, JSRC, EPI, MATH, WS, LOOP_ASM_TS>;
         return nullptr;
       }
+      if (loop == LOOP_ASM_PF) {  // L2 prefetch: same scope (one workgroup row, one wave per SIMD)
+        if (B == 2) return launch_force_t<T, 2, JSRC, EPI, MATH, WS, LOOP_ASM_PF>;
+        if (B == 4) return launch_force_t<T, 4, JSRC, EPI, MATH, WS, LOOP_ASM_PF>;
+        return nullptr;
+      }
     }
-    if (loop == LOOP_ASM_TS) loop = LOOP_ASM;  // e.g. nbx_accel's slab form of a time-sliced context
+    if (loop == LOOP_ASM_TS || loop == LOOP_ASM_PF) loop = LOOP_ASM;  // e.g. nbx_accel's slab form of a time-sliced context
     if (loop == LOOP_ASM) {
       if (B == 2) return launch_force_t<T, 2, JSRC, EPI, MATH, WS, LOOP_ASM>;
       if (B == 4) return launch_force_t<T, 4, JSRC, EPI, MATH, WS, LOOP_ASM>;
@@ -123,11 +132,18 @@ ForceLauncher<T> pick(int B, int variant, int epi, int loop) {
   return pick_epi<T, JSRC_LDS, MATH, false>(B, epi, loop);
 }
 
+// One body per lane on the plain SGPR kernel: its hand-scheduled loop packs two consecutive j records per operation and reads the
+// pair-interleaved copy of the records (nbx_ctx::posm_pairs)
+bool jpair_shape(const nbx_ctx* c) {
+  return c->precision == 32 && c->variant == NBX_KERNEL_SGPR && c->math == MATH_SCALAR && c->B == 1 && c->jps % kSgprAsmTrip<1> == 0;
+}
+
 // Does the hand-scheduled loop exist for this shape?  (mirror of kHasAsmLoop for run-time shape decisions)
 bool asm_loop_available(const nbx_ctx* c, int epi) {
   (void)epi;
   if (c->variant == NBX_KERNEL_JLANE) return c->precision == 32 && (c->B == 2 || c->B == 4 || c->B == 8);
   if (c->variant == NBX_KERNEL_SGPRW && c->jps % 256 != 0) return false;  // a wave walks a quarter of a split: whole trips only
+  if (jpair_shape(c)) return true;
   return c->precision == 32 && (c->variant == NBX_KERNEL_SGPR || c->variant == NBX_KERNEL_SGPRW) && c->math == MATH_PACKED && (c->B == 2 || c->B == 4);
 }
 
@@ -145,16 +161,22 @@ ForceLauncher<T> pick_force(const nbx_ctx* c, int epi) {
 // Bodies per lane of the reference-order kernel (one chain per owned body, S = 1).  Its run time is quantised: the
 // ceil(own / (256 B)) workgroups are spread over the CUs, and a launch takes as long as the fullest CU, which holds
 // r = ceil(workgroups / CUs) of them.  Measured on MI355X at n = 1048576 with the hand-scheduled loop for B = 2 and 4
-// (profiles/r02_reference_order_thresholds.txt), ms for r = 1, 2, 3, ...: B = 1: 31.0, 48.6, 70.3, 91, 112 (plain VALU ops);
-// B = 2: 31.5, 59.6, 88.5, 118;  B = 4: 59.3, 117.4, 175.6, 234.6 -- linear in r after the first workgroup.  With two workgroups on
-// the fullest CU the time-sliced loop applies (LOOP_ASM_TS): B = 2, r = 2 then costs 58.0 (profiles/r02_time_sliced_ab.txt: 57.98 ms for
-// 262144 of 1M bodies), B = 4, r = 2 117.0.  Pick the B with the smallest estimate; ties go to the larger B (fewer workgroups stream
-// the j records).  Only the ratios matter, so the table serves every n.
-int reference_order_bodies_per_lane(int own, int cus, int max_b) {
-  static const struct { int b; double first, next, two; } kCost[] = {{1, 31.0, 20.2, 0.0}, {2, 31.5, 28.8, 58.0}, {4, 59.8, 58.2, 117.0}};
+// (profiles/r02_reference_order_thresholds.txt), ms for r = 1, 2, 3, ...: B = 1, compiled loop: 31.0, 48.6, 70.3, 91, 112 (plain VALU ops);
+// B = 2: 31.5 (30.5 with the L2 prefetch of LOOP_ASM_PF, round 4), 59.6, 88.5, 118;  B = 4: 59.3, 117.4, 175.6, 234.6 -- linear in r after
+// the first workgroup.  With two workgroups on the fullest CU the time-sliced loop applies (LOOP_ASM_TS): B = 2, r = 2 then costs 58.0
+// (profiles/r02_time_sliced_ab.txt: 57.98 ms for 262144 of 1M bodies), B = 4, r = 2 117.0.  Round 4: one body per lane with the
+// two-j-records-per-operation loop (sgpr_loop_asm_jpair, `jpair`): 18.7 for r = 1 (65536 of 1M bodies: 46.8 % of the roofline against 28.4 %
+// for the compiled loop and 27.8 % for B = 2 on half the CUs), 37.6 for r = 2 (profiles/r04_jpair_ab.txt) -- so it takes every slice of up to
+// 256 x CUs = 65536 bodies, and B = 2 keeps 65537 ... 131072.  Pick the B with the smallest estimate; ties go to the larger B (fewer
+// workgroups stream the j records).  Only the ratios matter, so the table serves every n.
+int reference_order_bodies_per_lane(int own, int cus, int max_b, bool jpair) {
+  struct Cost { int b; double first, next, two; };
+  static const Cost kCost[] = {{1, 31.0, 20.2, 0.0}, {2, 30.5, 29.8, 58.0}, {4, 59.8, 58.2, 117.0}};
+  static const Cost kJpair = {1, 18.7, 18.9, 0.0};  // one body per lane, two j records per packed operation
   int best = 1;
   double best_t = 0.0;
-  for (const auto& k : kCost) {
+  for (const auto& k0 : kCost) {
+    const auto& k = (k0.b == 1 && jpair) ? kJpair : k0;
     if (k.b > max_b) continue;
     const int wgs = ceil_div(own, kBlock * k.b);
     const int r = std::max(1, ceil_div(wgs, std::max(1, cus)));
@@ -226,7 +248,9 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
     const int maxBr = c->precision == 32 ? 8 : 4;
     if (B != 1 && B != 2 && B != 4 && B != 8) B = 0;
     if (B > maxBr) B = maxBr;
-    if (B == 0) B = reference_order_bodies_per_lane(c->i_count, cus, maxBr);
+    // fp32, plain SGPR kernel, hand-scheduled loops allowed: one body per lane means sgpr_loop_asm_jpair
+    const bool jpair = c->precision == 32 && variant == NBX_KERNEL_SGPR && o.inner_loop != NBX_LOOP_CXX;
+    if (B == 0) B = reference_order_bodies_per_lane(c->i_count, cus, maxBr, jpair);
     c->B = B; c->S = 1; c->jps = c->n_alloc; c->variant = variant;
     c->math = (c->precision == 32 && B >= 2) ? MATH_PACKED : MATH_SCALAR;
     c->epi = o.fused_epilogue == 2 ? EPI_SLAB : EPI_ROW;
@@ -275,7 +299,7 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   // true sum than the reference's single chain -- and the number of chains is what buys that: n = 262144 keeps its 8 x 4, 1M its 2 x 4.
   const bool balanced = o.j_split <= 0 && c->precision == 32 && variant == NBX_KERNEL_SGPRW && c->i_count > kRound1SplitMaxOwn && c->n <= kTreeOrderMaxN;
   const int gran = variant == NBX_KERNEL_LDS ? kTile : (variant == NBX_KERNEL_SGPR ? 64 : (balanced ? 256 : 32));
-  static_assert(64 % kSgprAsmTrip<2> == 0 && 64 % kSgprAsmTrip<4> == 0 && kTile % 64 == 0, "j ranges are whole trips of the asm loop");
+  static_assert(64 % kSgprAsmTrip<2> == 0 && 64 % kSgprAsmTrip<4> == 0 && 64 % kSgprAsmTrip<1> == 0 && kTile % 64 == 0, "j ranges are whole trips of the asm loop");
   const int max_split = std::max(1, c->n_alloc / gran);
   int S = o.j_split;
   if (S <= 0) {
@@ -330,6 +354,14 @@ int enqueue_force(nbx_ctx* c, int epi, double dt) {
   a.n_alloc = c->n_alloc;
   a.dt = (T)dt;
   a.slice_bit = c->slice_bit;
+  a.posm_pairs = (const T4*)c->posm_pairs;
+  if constexpr (sizeof(T) == 4) {
+    if (c->loop == LOOP_ASM && jpair_shape(c)) {  // this step's pair-interleaved copy of the records (all n_alloc of them: other ranks' blocks arrived by all-gather)
+      const int npairs = c->n_alloc / 2;
+      hipLaunchKernelGGL(pair_transpose_kernel, dim3(ceil_div(npairs, kBlock)), dim3(kBlock), 0, c->stream, (const float4*)c->posm[c->cur],
+                         (float4*)c->posm_pairs, npairs);
+    }
+  }
   const bool prof = c->profiling && c->ev_used + 2 <= c->ev.size();
   if (prof) HIP_TRY(hipEventRecord(c->ev[c->ev_used], c->stream));
   if (c->variant == NBX_KERNEL_JLANE) {
@@ -598,22 +630,28 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
     c->own_stream = true;
   }
   auto_shape(c, o);
-  if (o.inner_loop != NBX_LOOP_AUTO && o.inner_loop != NBX_LOOP_CXX && o.inner_loop != NBX_LOOP_ASM && o.inner_loop != NBX_LOOP_ASM_TS)
-    return fail(NBX_ERR_ARG, "nbx_create: inner_loop must be NBX_LOOP_AUTO, NBX_LOOP_CXX, NBX_LOOP_ASM or NBX_LOOP_ASM_TS");
+  if (o.inner_loop != NBX_LOOP_AUTO && o.inner_loop != NBX_LOOP_CXX && o.inner_loop != NBX_LOOP_ASM && o.inner_loop != NBX_LOOP_ASM_TS &&
+      o.inner_loop != NBX_LOOP_ASM_PF)
+    return fail(NBX_ERR_ARG, "nbx_create: inner_loop must be NBX_LOOP_AUTO, NBX_LOOP_CXX, NBX_LOOP_ASM, NBX_LOOP_ASM_TS or NBX_LOOP_ASM_PF");
   c->loop = (o.inner_loop != NBX_LOOP_CXX && asm_loop_available(c, c->epi)) ? LOOP_ASM : LOOP_CXX;
-  if ((o.inner_loop == NBX_LOOP_ASM || o.inner_loop == NBX_LOOP_ASM_TS) && c->loop != LOOP_ASM)
-    return fail(NBX_ERR_ARG, "nbx_create: no hand-scheduled loop for this shape (needs fp32; kernel_variant SGPR or SGPRW with j_per_split a multiple of 256 and 2 or 4 bodies per lane, or JLANE with 2, 4 or 8 bodies per wave)");
+  if ((o.inner_loop == NBX_LOOP_ASM || o.inner_loop == NBX_LOOP_ASM_TS || o.inner_loop == NBX_LOOP_ASM_PF) && c->loop != LOOP_ASM)
+    return fail(NBX_ERR_ARG, "nbx_create: no hand-scheduled loop for this shape (needs fp32; kernel_variant SGPR with 1, 2 or 4 bodies per lane, SGPRW with j_per_split a multiple of 256 and 2 or 4 bodies per lane, or JLANE with 2, 4 or 8 bodies per wave)");
   // Time-sliced wave priority (LOOP_ASM_TS) exists for the row-epilogue SGPR kernel: one workgroup row, every wave resident
   // from the first cycle to the last.  Auto takes it when the fullest CU holds exactly two workgroups, i.e. two waves per
   // SIMD: measured +4.5 % at 512 workgroups, +2.7 % at 384, -0.6 % with one wave per SIMD (nobody to alternate with, six
   // more scalar instructions per trip) and -0.6 ... +0.3 % with three, four or eight (profiles/r02_time_sliced_ab.txt).
   {
-    const bool ts_shape = c->loop == LOOP_ASM && c->variant == NBX_KERNEL_SGPR && c->epi == EPI_ROW;
+    const bool ts_shape = c->loop == LOOP_ASM && c->variant == NBX_KERNEL_SGPR && c->epi == EPI_ROW && c->B >= 2;
     if (o.inner_loop == NBX_LOOP_ASM_TS && !ts_shape)
       return fail(NBX_ERR_ARG, "nbx_create: NBX_LOOP_ASM_TS needs the single-row SGPR kernel (reference summation order or j_split 1, fp32, 2 or 4 bodies per lane)");
     const int cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
     const bool two_per_simd = (int)c->grid.x > cus && (int)c->grid.x <= 2 * cus;
     if (ts_shape && (o.inner_loop == NBX_LOOP_ASM_TS || (o.inner_loop == NBX_LOOP_AUTO && two_per_simd))) c->loop = LOOP_ASM_TS;
+    // L2 prefetch (LOOP_ASM_PF): the same kernels when the launch leaves one wave per SIMD -- a rank that owns 131072 of 1M bodies:
+    // +3.5 %; with two or more waves per SIMD the other waves are the cover and it costs 0.4-1.4 % (profiles/r04_b2_prefetch_ab.txt)
+    if (o.inner_loop == NBX_LOOP_ASM_PF && !ts_shape)
+      return fail(NBX_ERR_ARG, "nbx_create: NBX_LOOP_ASM_PF needs the single-row SGPR kernel (reference summation order or j_split 1, fp32, 2 or 4 bodies per lane)");
+    if (ts_shape && (o.inner_loop == NBX_LOOP_ASM_PF || (o.inner_loop == NBX_LOOP_AUTO && (int)c->grid.x <= cus))) c->loop = LOOP_ASM_PF;
   }
   c->slice_bit = kSliceBit;
   if (const char* e = getenv("NBX_SLICE_BIT")) {  // experiments: log2 of the slice length in 10 ns units
@@ -645,6 +683,10 @@ int nbx_create(nbx_ctx** out, int32_t n, int32_t precision, const nbx_opts* opts
   const int max_parts = std::max(ceil_div(c->i_count, kBlock), (int)c->grid.x);
   CREATE_TRY(hipMalloc(&c->ke_part, sizeof(double) * (size_t)max_parts));
   if (c->variant == NBX_KERNEL_EXACT || c->variant == NBX_KERNEL_EXACT_FMA) CREATE_TRY(hipMalloc(&c->mass_all, (c->rec / 4) * (size_t)c->n_alloc));
+  if (c->loop == LOOP_ASM && jpair_shape(c)) {  // same size and the same zero-filled spare records as posm
+    CREATE_TRY(hipMalloc(&c->posm_pairs, pos_bytes));
+    CREATE_TRY(hipMemsetAsync(c->posm_pairs, 0, pos_bytes, c->stream));
+  }
   CREATE_TRY(hipMemsetAsync(c->posm[0], 0, pos_bytes, c->stream));
   CREATE_TRY(hipMemsetAsync(c->posm[1], 0, pos_bytes, c->stream));
   CREATE_TRY(hipMemsetAsync(c->ke_part, 0, sizeof(double) * (size_t)max_parts, c->stream));
@@ -670,6 +712,7 @@ void nbx_destroy(nbx_ctx* c) {
   if (c->accp) (void)hipFree(c->accp);
   if (c->ke_part) (void)hipFree(c->ke_part);
   if (c->mass_all) (void)hipFree(c->mass_all);
+  if (c->posm_pairs) (void)hipFree(c->posm_pairs);
   if (c->ke_dev) (void)hipFree(c->ke_dev);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -909,7 +952,7 @@ int nbx_stats(nbx_ctx* c, nbx_stats_t* s) {
   s->pairs_per_launch = (double)c->i_count * (double)c->n;
   s->graph_replays = c->graph_replays;
   s->use_graph = c->use_graph ? 1 : 0;
-  s->inner_loop = c->loop == LOOP_ASM_TS ? NBX_LOOP_ASM_TS : c->loop == LOOP_ASM ? NBX_LOOP_ASM : NBX_LOOP_CXX;
+  s->inner_loop = c->loop == LOOP_ASM_TS ? NBX_LOOP_ASM_TS : c->loop == LOOP_ASM_PF ? NBX_LOOP_ASM_PF : c->loop == LOOP_ASM ? NBX_LOOP_ASM : NBX_LOOP_CXX;
   // some boxes report an empty marketing name; fall back to / append the ISA name
   std::snprintf(s->device_name, sizeof(s->device_name), "%s%s%s", c->prop.name, c->prop.name[0] ? " " : "",
                 c->prop.gcnArchName);

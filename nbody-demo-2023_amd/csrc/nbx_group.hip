@@ -365,6 +365,11 @@ int nbx_group_step(nbx_group* g, double dt, int32_t nsteps, double* kenergy_out)
   const auto t_enter = std::chrono::steady_clock::now();
   const bool window_from_sync = g->steps_unsynced == 0;  // everything this call waits for was enqueued by this call
   g->steps_unsynced += nsteps;
+  // Groups that exchange over RCCL are bounded from the FIRST enqueue on, not only at the final synchronisation: the first
+  // collective of a communicator sets its channels up on the host inside ncclGroupEnd / ncclAllGather, and a full launch queue
+  // blocks the host in hipLaunchKernel -- a peer that died after ncclCommInitRank would otherwise leave this rank in the loop
+  // below, which never reaches an armed region (and never at all when kenergy_out == NULL).  Scopes nest: the inner ones stay.
+  Watchdog::Scope bounded_enqueue(g->use_rccl, "nbx_group_step (enqueue: local steps + position all-gathers)", queued_allowance(g));
   for (int s = 0; s < nsteps; ++s) {
     for (nbx_ctx* c : g->rank) {
       const int rc = nbx_step_local(c, dt);

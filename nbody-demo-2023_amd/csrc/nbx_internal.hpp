@@ -61,6 +61,7 @@ struct nbx_ctx {
   void* accp = nullptr;
   double* ke_part = nullptr;
   void* mass_all = nullptr;        // NBX_KERNEL_EXACT only: m of every body (the records carry G*m)
+  void* posm_pairs = nullptr;      // one body per lane + hand-scheduled loop only: pair-interleaved copy of posm[cur], rebuilt every step
   int ke_parts = 0;       // partials written by the last step
   double* ke_dev = nullptr;  // [ke_cap] reduced sums (sum m v^2)
   int ke_cap = 0;

@@ -189,6 +189,7 @@ struct ForceArgs {
                                      // LDS source, of 4*kSgprBatch (2*kSgprBatch per wave under WSPLIT) for the SGPR one
   int n_alloc;                       // multiple of kTile
   T dt;
+  const typename V4<T>::type* posm_pairs;  // LOOP_ASM with one body per lane: the pair-interleaved copy of posm (pair_transpose_kernel)
   unsigned slice_bit;                // LOOP_ASM_TS: clock bit of the priority slices (kSliceBit unless NBX_SLICE_BIT overrides)
 };
 
@@ -242,12 +243,19 @@ enum : int { MATH_SCALAR = 0, MATH_PACKED = 1 };
 // gfx950 loop of nbx_sgpr_loop.inc (packed fp32, B = 2 or 4, no wave split): same operations in the same order, hence
 // the same bits (tests compare the two), but no s_mov splats, one pointer update per trip and 8-byte aligned VOP3P code:
 // worth 13 % when a SIMD holds a single wave, where every scalar instruction costs a full 4-cycle issue slot.
+// With ONE body per lane LOOP_ASM is the two-j-records-per-packed-operation loop (sgpr_loop_asm_jpair): slices that leave less than
+// one wave per SIMD at two bodies per lane (<= 65536 owned bodies) get twice the waves at 76 cycles per two pairs instead of 2 x 56;
+// it reads the pair-interleaved copy of the records that pair_transpose_kernel rebuilds every step.
 // LOOP_ASM_TS = the same loop with time-sliced wave priority, for shapes that put two waves on a SIMD for the whole launch
 // (reference order, grid.y == 1, 257..512 workgroups on 256 CUs): this chip issues the waves of a SIMD in strict age order,
 // so without it they run one after the other -- the older one leaves the loop at 0.50 of the kernel time -- and the younger
 // one has nobody to fill its issue bubbles (tools/wave_fair.hip).  +4.5 % at n = 262144; nothing to gain
 // with one wave per SIMD (-0.6 %: the six scalar instructions) or with three and more (profiles/r02_time_sliced_ab.txt).
-enum : int { LOOP_CXX = 0, LOOP_ASM = 1, LOOP_ASM_TS = 2 };
+// LOOP_ASM_PF = the same loop plus one L2-prefetch load per trip, for launches that leave ONE wave per SIMD (grid.x <= CUs, e.g. a rank
+// that owns 131072 of 1M bodies): there the arithmetic of one ring group (512 cycles) is all the cover a scalar load gets, every wave of
+// an XCD asks for the same line at about the same time, and what they all wait for is the first requester's Infinity-Cache round trip
+// (~545 cycles).  +3.5 % at one wave per SIMD, -0.4 ... -1.4 % with two or more (profiles/r04_b2_prefetch_ab.txt).
+enum : int { LOOP_CXX = 0, LOOP_ASM = 1, LOOP_ASM_TS = 2, LOOP_ASM_PF = 3 };
 // clock bit (s_memrealtime counts 10 ns) that selects the favoured slot parity: slices of 2^16 x 10 ns = 0.66 ms.  Measured
 // 2^14 ... 2^19 within 1 % of each other, 2^16-2^17 best; shorter slices lose to the time the unfavoured wave needs to reach
 // its next decision, longer ones to the imbalance of the last slice.
@@ -297,6 +305,12 @@ struct IBodies<float, B, MATH_PACKED> {
     if constexpr (B == 2) sgpr_loop_asm_b2(first, last, xi[0], yi[0], zi[0], ax[0], ay[0], az[0]);
     else sgpr_loop_asm_b4(first, last, xi[0], yi[0], zi[0], xi[1], yi[1], zi[1], ax[0], ay[0], az[0], ax[1], ay[1], az[1]);
   }
+  // the same with the L2 prefetch (LOOP_ASM_PF)
+  __device__ __forceinline__ void apply_range_asm_pf(const float4* first, const float4* last) {
+    static_assert(B == 2 || B == 4, "the asm loop exists for 2 and 4 bodies per lane");
+    if constexpr (B == 2) sgpr_loop_asm_b2_pf(first, last, xi[0], yi[0], zi[0], ax[0], ay[0], az[0]);
+    else sgpr_loop_asm_b4_pf(first, last, xi[0], yi[0], zi[0], xi[1], yi[1], zi[1], ax[0], ay[0], az[0], ax[1], ay[1], az[1]);
+  }
   // the same with time-sliced wave priority (LOOP_ASM_TS); slot_bit = slice_bit for waves in odd slots of their SIMD, else 0
   __device__ __forceinline__ void apply_range_asm_ts(const float4* first, const float4* last, unsigned slice_bit, unsigned slot_bit) {
     static_assert(B == 2 || B == 4, "the asm loop exists for 2 and 4 bodies per lane");
@@ -318,8 +332,9 @@ template <typename T, int B, int JSRC, int EPI, int MINW, int MATH = MATH_SCALAR
 __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> a) {
   using T4 = typename V4<T>::type;
   static_assert(!WSPLIT || (JSRC == JSRC_SGPR && EPI != EPI_ROW), "wave split exists for the SGPR kernel with slabs only");
-  static_assert(LOOP == LOOP_CXX || (JSRC == JSRC_SGPR && MATH == MATH_PACKED && sizeof(T) == 4 && (B == 2 || B == 4)),
-                "the hand-scheduled loop exists for the packed fp32 SGPR kernels with 2 or 4 bodies per lane");
+  static_assert(LOOP == LOOP_CXX || (JSRC == JSRC_SGPR && MATH == MATH_PACKED && sizeof(T) == 4 && (B == 2 || B == 4)) ||
+                    (LOOP == LOOP_ASM && JSRC == JSRC_SGPR && MATH == MATH_SCALAR && sizeof(T) == 4 && B == 1 && !WSPLIT),
+                "the hand-scheduled loop exists for the packed fp32 SGPR kernels with 2 or 4 bodies per lane, and as the two-records-per-operation loop for 1");
   const int t = threadIdx.x;
   constexpr int kStride = WSPLIT ? 64 : kBlock;  // distance between a lane's consecutive bodies
   const int base = blockIdx.x * (kStride * B) + (WSPLIT ? (t & 63) : t);
@@ -367,7 +382,14 @@ __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> 
   } else if constexpr (LOOP == LOOP_ASM) {
     // j range = a positive multiple of kSgprAsmTrip<B> records (the host rounds j_per_split to 64, to 256 under WSPLIT where a
     // wave walks a quarter of it; n_alloc is a multiple of 256)
-    if (j0 < j1) ib.apply_range_asm(a.posm + j0, a.posm + j1);
+    if constexpr (B == 1) {
+      // one body per lane: two consecutive j records per packed operation, out of the pair-interleaved copy (same offsets)
+      if (j0 < j1) sgpr_loop_asm_jpair(a.posm_pairs + j0, a.posm_pairs + j1, f32x2{ib.xi[0], ib.yi[0]}, f32x2{ib.zi[0], ib.zi[0]}, (unsigned)(t & 15) * 64u, ib.ax[0], ib.ay[0], ib.az[0]);
+    } else {
+      if (j0 < j1) ib.apply_range_asm(a.posm + j0, a.posm + j1);
+    }
+  } else if constexpr (LOOP == LOOP_ASM_PF) {
+    if (j0 < j1) ib.apply_range_asm_pf(a.posm + j0, a.posm + j1);
   } else if constexpr (LOOP == LOOP_ASM_TS) {
     if (j0 < j1) {
       unsigned hwid;
@@ -758,6 +780,21 @@ __global__ __launch_bounds__(kBlock) void force_exact_kernel(const typename V4<T
   accp[li] = r;
 }
 #undef NBX_EXACT_ROW
+
+// ---------------------------------------------------------------------------------------------
+// pair_transpose_kernel: the pair-interleaved copy of the record array that sgpr_loop_asm_jpair reads.  Records 2k and 2k+1,
+// {x0 y0 z0 w0}{x1 y1 z1 w1}, become {x0 x1 y0 y1}{z0 z1 w0 w1} at the same byte offset: a packed operand is one aligned 64-bit
+// register pair, so the two records a packed instruction works on must be neighbours component by component.  One thread per
+// pair, 32 B in and 32 B out, once per step in front of the force launch (n = 1M: 32 MiB of L2 / Infinity-Cache traffic, ~10 us
+// against a 15 ms step); npairs = n_alloc / 2 (the spare records behind the array stay zero in both layouts).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void pair_transpose_kernel(const float4* __restrict__ posm, float4* __restrict__ pairs, int npairs) {
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  if (k >= npairs) return;
+  const float4 a = posm[2 * k], b = posm[2 * k + 1];
+  pairs[2 * k] = make_float4(a.x, b.x, a.y, b.y);
+  pairs[2 * k + 1] = make_float4(a.z, b.z, a.w, b.w);
+}
 
 // ---------------------------------------------------------------------------------------------
 // integrate_kernel: one body per thread; sums the S partial accelerations in split order.

@@ -58,9 +58,14 @@ class Watchdog {
   class Scope {
    public:
     explicit Scope(const char* what, double allowance_s = 0.0) { Watchdog::instance().arm(what, allowance_s); }
-    ~Scope() { Watchdog::instance().disarm(); }
+    // a scope that only exists under a run-time condition (e.g. "this group exchanges over RCCL")
+    Scope(bool enabled, const char* what, double allowance_s) : on_(enabled) { if (on_) Watchdog::instance().arm(what, allowance_s); }
+    ~Scope() { if (on_) Watchdog::instance().disarm(); }
     Scope(const Scope&) = delete;
     Scope& operator=(const Scope&) = delete;
+
+   private:
+    bool on_ = true;
   };
 
  private:

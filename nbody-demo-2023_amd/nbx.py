@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("NBX_LIB") or os.path.join(_HERE, "libnbx.so")
 
 NBX_OK, NBX_ERR_ARG, NBX_ERR_DEVICE, NBX_ERR_STATE, NBX_ERR_ALLOC = 0, -1, -2, -3, -4
 ORDER_AUTO, ORDER_REFERENCE, ORDER_TREE = 0, 1, 2
-LOOP_AUTO, LOOP_CXX, LOOP_ASM, LOOP_ASM_TS = 0, 1, 2, 3
+LOOP_AUTO, LOOP_CXX, LOOP_ASM, LOOP_ASM_TS, LOOP_ASM_PF = 0, 1, 2, 3, 4
 KERNEL_AUTO, KERNEL_LDS, KERNEL_SGPR, KERNEL_SGPRW, KERNEL_EXACT, KERNEL_EXACT_FMA, KERNEL_JLANE = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/nbx.h declares (tests check the library exports each of them)

@@ -1232,7 +1232,9 @@ def test_reference_order_is_partition_independent_bit_for_bit(nbx, prec):
         ke = c.step(steps)
         ref = c.download()
     for opts in (dict(kernel_variant=nbx.KERNEL_LDS, bodies_per_lane=1), dict(kernel_variant=nbx.KERNEL_SGPR, bodies_per_lane=4),
-                 dict(kernel_variant=nbx.KERNEL_LDS, bodies_per_lane=4, fused_epilogue=2), dict(use_graph=1)):
+                 dict(kernel_variant=nbx.KERNEL_LDS, bodies_per_lane=4, fused_epilogue=2), dict(use_graph=1),
+                 dict(kernel_variant=nbx.KERNEL_SGPR, bodies_per_lane=1),                      # fp32: two j records per packed operation
+                 dict(kernel_variant=nbx.KERNEL_SGPR, bodies_per_lane=1, use_graph=1, fused_epilogue=2)):
         with nbx.Context(n, prec, summation_order=nbx.ORDER_REFERENCE, **opts) as c:
             c.upload(ic)
             c.step(steps, kenergy=False)
@@ -1249,6 +1251,37 @@ def test_reference_order_is_partition_independent_bit_for_bit(nbx, prec):
     assert abs(keg / ke - 1.0) < 1e-13
 
 
+def test_eight_ranks_of_config2_with_the_two_records_per_operation_loop_against_the_real_reference(nbx):
+    """n = 262144 on 8 ranks = 32768 bodies per rank: half a wave per SIMD with two bodies per lane, so every rank takes one body per
+    lane and the two-j-records-per-operation loop (sgpr_loop_asm_jpair).  All 200 steps of BASELINE configs[2] as 8 logical ranks
+    against the trace of the reference's own binary (tests/golden/ver7_f32_n262144_s200.json, gate 1e-4), and the final state bit
+    for bit against the one-context run (two bodies per lane, time-sliced loop): reference order is partition independent."""
+    if not os.path.exists(_CONFIG2_FIXTURE):
+        pytest.skip("fixture of the full configs[2] run not generated")
+    g = load_golden("ver7_f32_n262144_s200.json")
+    n, steps = g["n"], g["nsteps"]
+    assert n == 262144 and steps == 200
+    ref = np.array(g["kenergy"])
+    ic = nbx.initial_conditions(n)
+    with nbx.Group(n, 32, n_ranks=8) as grp:
+        grp.upload(ic)
+        P, _, st = grp.info(3)
+        assert P == 8 and st["i_count"] == 32768 and st["bodies_per_lane"] == 1 and st["inner_loop"] == nbx.LOOP_ASM
+        assert st["kernel_variant"] == nbx.KERNEL_SGPR and st["summation_order"] == nbx.ORDER_REFERENCE and st["force_grid_x"] == 128
+        ke = np.array([grp.step(1) for _ in range(steps)])
+        d8 = grp.download()
+    e = rel_err(ke, ref)
+    assert e.max() < 1e-4, (int(e.argmax()) + 1, e.max())          # measured 4.9e-5, as the one-context run
+    with nbx.Context(n, 32) as c:
+        c.upload(ic)
+        assert c.stats()["bodies_per_lane"] == 2
+        ke1 = c.step(steps)
+        d1 = c.download()
+    for f in d1:
+        assert np.array_equal(d8[f], d1[f]), f
+    assert abs(ke[-1] / ke1 - 1.0) < 1e-13
+
+
 def test_auto_order_threshold(nbx):
     for n, want in ((131072, nbx.ORDER_TREE), (131073, nbx.ORDER_REFERENCE), (262144, nbx.ORDER_REFERENCE)):
         with nbx.Context(n) as c:
@@ -1257,6 +1290,10 @@ def test_auto_order_threshold(nbx):
     with nbx.Context(262144, i_begin=65536, i_count=32768, n_alloc=262144) as c:
         st = c.stats()
         assert st["summation_order"] == nbx.ORDER_REFERENCE and st["j_split"] == 1 and st["bodies_per_lane"] == 1
+        assert st["inner_loop"] == nbx.LOOP_ASM and st["kernel_variant"] == nbx.KERNEL_SGPR  # two j records per packed operation
+    for own, B in ((65536, 1), (65537, 2), (49152, 1), (131072, 2)):   # one body per lane up to one workgroup per CU, two from there
+        with nbx.Context(1048576, i_begin=0, i_count=own, n_alloc=1048576) as c:
+            assert c.stats()["bodies_per_lane"] == B, own
     with nbx.Context(131072, i_begin=0, i_count=16384, n_alloc=131072) as c:
         assert c.stats()["summation_order"] == nbx.ORDER_TREE
     with nbx.Context(1048576, i_begin=0, i_count=131072, n_alloc=1048576) as c:      # one rank of the 8-GPU configuration
@@ -1318,11 +1355,14 @@ def test_randomized_shapes_orders_and_sizes_against_exact_mode(nbx):
 # ---- the hand-scheduled j loop (nbx_sgpr_loop.inc) against the compiler-scheduled one ------------------------------
 @pytest.mark.parametrize("n,own,steps", [(2000, 2000, 40), (4099, 4099, 25), (16384, 16384, 12), (65536, 65536, 4), (300, 300, 30),
                                           (262144, 32768, 2)])
-@pytest.mark.parametrize("B", [2, 4])
+@pytest.mark.parametrize("B", [1, 2, 4])
 def test_hand_scheduled_loop_is_bit_equal_to_the_compiled_loop(nbx, n, own, steps, B):
     """inner_loop = NBX_LOOP_ASM runs the same operations in the same order as the C++ loop: accelerations, trajectories
     and energies must agree bit for bit, for the row epilogue (reference order), for slabs (j-splits) and on a slice.
-    This is also the hazard check of the asm stream: a consumer issued too close to its producer would change bits."""
+    This is also the hazard check of the asm stream: a consumer issued too close to its producer would change bits.
+    B = 1 is the two-j-records-per-packed-operation loop (round 4): records j and j + 1 of ONE body in the two halves of each
+    packed instruction, out of the pair-interleaved copy of the records, the two terms added in ascending j -- against the
+    compiled one-body-per-lane loop with its plain (unpacked) instructions."""
     ic = nbx.initial_conditions(n)
     for shape in (dict(j_split=1), dict(j_split=1, fused_epilogue=2), dict(j_split=3), dict(j_split=16)):
         res = []
@@ -1452,7 +1492,7 @@ def test_time_sliced_wave_priority_changes_no_bit(nbx, n, own, steps, B):
     workgroups), with one (262144 x B4, 131072 x B2: 256 workgroups), on small grids and on a slice of a larger system."""
     ic = nbx.initial_conditions(n)
     res = []
-    for loop in (nbx.LOOP_ASM_TS, nbx.LOOP_ASM, nbx.LOOP_CXX):
+    for loop in (nbx.LOOP_ASM_TS, nbx.LOOP_ASM, nbx.LOOP_CXX, nbx.LOOP_ASM_PF):  # ASM_PF (round 4): the plain loop + one L2-prefetch load per trip
         with nbx.Context(n, 32, kernel_variant=nbx.KERNEL_SGPR, bodies_per_lane=B, inner_loop=loop, use_graph=2, j_split=1,
                          i_begin=0, i_count=own, n_alloc=n) as c:
             c.upload(ic)
@@ -1464,7 +1504,7 @@ def test_time_sliced_wave_priority_changes_no_bit(nbx, n, own, steps, B):
             st = c.stats()
             assert st["inner_loop"] == loop and st["bodies_per_lane"] == B and st["force_grid_y"] == 1
             res.append((acc, c.download(), part))
-    for other in (1, 2):
+    for other in (1, 2, 3):
         for k in range(3):
             assert np.array_equal(res[0][0][k], res[other][0][k]), (other, "acc", k)
         for f in res[0][1]:
@@ -1500,9 +1540,13 @@ def test_hand_scheduled_loop_is_the_default_where_it_exists(nbx):
         assert st["summation_order"] == nbx.ORDER_REFERENCE and st["inner_loop"] == nbx.LOOP_ASM_TS
     with nbx.Context(1048576, 32, i_begin=0, i_count=131072, n_alloc=1048576) as c:  # one rank of eight: one wave per SIMD
         st = c.stats()
-        assert st["summation_order"] == nbx.ORDER_REFERENCE and st["inner_loop"] == nbx.LOOP_ASM
+        assert st["summation_order"] == nbx.ORDER_REFERENCE and st["inner_loop"] == nbx.LOOP_ASM_PF  # with the L2 prefetch
+    with nbx.Context(1048576, 32) as c:  # four waves per SIMD: the plain loop
+        assert c.stats()["inner_loop"] == nbx.LOOP_ASM
     with pytest.raises(nbx.NbxError):
         nbx.Context(65536, 32, kernel_variant=nbx.KERNEL_SGPRW, inner_loop=nbx.LOOP_ASM_TS)  # single-row SGPR kernel only
+    with pytest.raises(nbx.NbxError):
+        nbx.Context(65536, 32, kernel_variant=nbx.KERNEL_SGPRW, inner_loop=nbx.LOOP_ASM_PF)
     with nbx.Context(65536, 32) as c:  # tree order, wave-split kernel: 2048 records per split
         st = c.stats()
         assert st["kernel_variant"] == nbx.KERNEL_SGPRW and st["inner_loop"] == nbx.LOOP_ASM

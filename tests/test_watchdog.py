@@ -71,6 +71,23 @@ def test_inner_scopes_do_not_push_the_outer_deadline_back(driver):
     assert "rank 1 of 4 has been inside outer call" in p.stderr
 
 
+def test_a_rank_stuck_in_the_enqueue_loop_is_bounded_too(driver):
+    """nbx_group_step used to arm the watchdog only at its final synchronisation (and only when an energy was asked
+    for).  The first all-gather of a communicator does its channel set-up on the host inside ncclGroupEnd, and a full launch queue
+    blocks hipLaunchKernel: a peer that died after ncclCommInitRank left the rank inside the enqueue loop, unbounded.  The loop is
+    now inside a scope of its own whenever the group exchanges over RCCL; a copy-path group (one process, nobody to wait for)
+    arms nothing."""
+    t0 = time.time()
+    p = subprocess.run([driver, "enqueue", "2", "1"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == EXIT and 1.9 < time.time() - t0 < 8
+    assert "rank 1 of 2 has been inside nbx_group_step (enqueue: local steps + position all-gathers)" in p.stderr
+    p = subprocess.run([driver, "enqueue", "1", "0"], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0 and p.stdout.strip() == "done" and p.stderr == ""
+    src = open(os.path.join(CSRC, "nbx_group.hip")).read()
+    body = src[src.index("int nbx_group_step("):src.index("int nbx_group_download(")]
+    assert body.index("Watchdog::Scope bounded_enqueue(g->use_rccl") < body.index("nbx_step_local(c, dt)")   # armed before the first enqueue
+
+
 def test_rank_that_dies_after_the_rendezvous_does_not_leave_rank_zero_hanging(driver):
     """VERDICT r2 item 3 on CPU: two processes complete nbody.x's rendezvous; rank 1 then exits (a rank that died); rank 0
     enters the collective alone and ends non-zero within the timeout instead of waiting for ever."""

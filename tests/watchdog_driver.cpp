@@ -4,6 +4,9 @@
 //   watchdog_driver off                                    timeout 0: a scope that outlives everything is left alone
 //   watchdog_driver allowance <timeout_s> <allowance_s> <sleep_s>   a scope longer than the timeout but inside timeout + allowance
 //   watchdog_driver nested <timeout_s>                     the outer scope's deadline holds while inner scopes come and go
+//   watchdog_driver enqueue <timeout_s> <rccl 0|1>         the shape of nbx_group_step: a conditional outer scope around the enqueue loop (armed
+//                                                          only for groups that exchange over RCCL), the stand-in blocks INSIDE the loop, before
+//                                                          the inner scope at the synchronisation point is ever reached
 //   watchdog_driver rdv <rank> <world> <port> <timeout_s>  the start-up rendezvous of nbody.x (host/rendezvous.hpp), after which
 //                                                          rank 0 enters a collective its peers never join (they exit at once,
 //                                                          as a rank that died after the rendezvous)
@@ -68,6 +71,22 @@ int main(int argc, char** argv) {
     Watchdog::instance().set_identity(1, 4);
     Watchdog::Scope outer("outer call");
     for (;;) { Watchdog::Scope inner("inner call"); nap(0.05); }  // inner scopes must not push the outer deadline back
+  }
+  if (mode == "enqueue" && argc > 3) {
+    const double t = std::atof(argv[2]);
+    const bool rccl = std::atoi(argv[3]) != 0;
+    Watchdog::instance().set_timeout(t);
+    Watchdog::instance().set_identity(1, 2);
+    Watchdog::Scope enqueue(rccl, "nbx_group_step (enqueue: local steps + position all-gathers)", 0.0);
+    for (int s = 0; s < 3; ++s) {
+      if (s == 1) {              // "ncclGroupEnd of the first all-gather with a dead peer" / "a full launch queue"
+        if (rccl) block_for_ever();
+        nap(2.0 * t);            // a copy-path group has nothing that can wait for a peer: nothing is armed, nothing fires
+      }
+    }
+    { Watchdog::Scope sync("nbx_group_step (stream synchronisation)"); }
+    std::printf("done\n");
+    return 0;
   }
   if (mode == "rdv" && argc > 5) {
     const int rank = std::atoi(argv[2]), world = std::atoi(argv[3]), port = std::atoi(argv[4]);

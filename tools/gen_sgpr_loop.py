@@ -27,6 +27,19 @@ alone afterwards with nobody to fill its issue bubbles).  Once per trip the wave
 when (clock & slice_bit) equals the parity of its wave slot, priority 0 otherwise: each of two waves is the favoured one
 half of the time, both stay resident to the end and fill each other's bubbles.  Six more scalar instructions per trip;
 the arithmetic is untouched (same bits).  s[26:27] = clock.
+
+Two-j-records-per-operation variant (sgpr_loop_asm_jpair, round 4): ONE body per lane, for slices that leave less than
+one wave per SIMD with two bodies per lane (<= 65536 owned bodies: the reference summation order gives one chain per
+owned body and nothing else to parallelise over).  The plain B = 1 kernel issues 12 unpacked VALU + 1 v_rsq_f32 per
+pair = 56 cycles; here the packed lanes hold two CONSECUTIVE j records of the same body instead of two bodies: 9 packed
+instructions + 2 v_rsq_f32 produce (dx, dy, dz, s) of records j and j + 1, and six plain v_fmac_f32 add the two terms to
+the single accumulator in ascending j -- 76 cycles per two pairs, the operations and the order of pair<float>() exactly
+(same bits as every other reference-order shape).  A packed operand is one aligned 64-bit register pair, so x_j and
+x_{j+1} must be neighbours: the loop reads a pair-interleaved copy of the record array, {x0 x1 y0 y1 | z0 z1 w0 w1} per
+two records (pair_transpose_kernel rebuilds it once per step: 32 B per record of L2 traffic against 76 n cycles of
+arithmetic).  Four records (two such blocks) are interleaved instruction by instruction.  4-byte VALU encodings
+(v_rsq_f32_e32, v_fmac_f32_e32) come in even runs; where a lone s_waitcnt follows, the first v_fmac of the run is
+written in its 8-byte VOP3 form (v_fma_f32) instead of spending an s_nop on the alignment.
 """
 import os
 import sys
@@ -35,6 +48,8 @@ TBASE = 40            # first temporary VGPR (even)
 RING_A, RING_B = 36, 68
 SP, SE, SEPS = 30, 28, 34
 NEG = "neg_lo:[0,1] neg_hi:[0,1]"
+SGPR_PREFETCH = int(os.environ.get("NBX_SGPR_PREFETCH", "2"))  # B = 2 / 4 loops, _pf variants: trips ahead of the L2 prefetch
+JPAIR_GROUPS = int(os.environ.get("NBX_JPAIR_GROUPS", "8"))  # ring groups (8 records each) per trip of the jpair loop
 
 
 def tmp(slot, k):
@@ -104,7 +119,7 @@ WAIT = "s_waitcnt lgkmcnt(0)"
 STIME = 26
 
 
-def loop_text(B, groups_per_trip, ts=False):
+def loop_text(B, groups_per_trip, ts=False, pf=False):
     """groups_per_trip even; a trip covers 8*groups_per_trip records = trip_bytes of the record array.
     ts: once per trip, wave priority from the clock (operands %MASK = slice bit, %PAR = that bit if the wave's slot is odd)."""
     assert groups_per_trip % 2 == 0 and groups_per_trip >= 2
@@ -118,6 +133,12 @@ def loop_text(B, groups_per_trip, ts=False):
     body = []
     # group 0 (ring A) is resident at the loop head; group g+1 is requested before group g is consumed
     body += loads(RING_B, trip + 128)
+    if pf:
+        # L2 prefetch (see the jpair docstring paragraph): one vector load per trip, lane l touching byte 64 (l mod 16) of the trip
+        # SGPR_PREFETCH trips ahead; never waited on inside the loop, destination never read
+        off = trip + SGPR_PREFETCH * trip
+        assert off <= 4095 and (SGPR_PREFETCH + 1) * (trip // 16) <= 512
+        body += ["global_load_dword v%d, %%%d, s[%d:%d] offset:%d" % (TBASE + 24, (8 if B == 2 else 14) + (2 if ts else 0), SP, SP + 1, off)]
     if ts:
         body += ["s_memrealtime s[%d:%d]" % (STIME, STIME + 1)]
     body += group_ops(B, RING_A)
@@ -179,12 +200,123 @@ def check_distance(body):
         prev_defs = set(dst)
 
 
-def emit(B, groups_per_trip, ts=False):
-    pro, body, trip = loop_text(B, groups_per_trip, ts)
+def jpair_block_ops(slot, rbase, xy, zz, ax, ay, az, wide_first):
+    """One pair-interleaved block s[rbase:rbase+7] = {x0 x1 y0 y1 z0 z1 w0 w1} applied to ONE body (xy = {xi, yi}, zz = {zi, -}):
+    the operations of pair<float>() for record 2k in the low halves and record 2k+1 in the high halves, then the six
+    accumulator updates in ascending record order.  wide_first: first v_fmac in its 8-byte form (alignment, see docstring)."""
+    sx, sy, sz, sw = ("s[%d:%d]" % (rbase + 2 * k, rbase + 2 * k + 1) for k in range(4))
+    (dx, dxl, dxh), (dy, dyl, dyh), (dz, dzl, dzh), (r2, r2l, r2h), (q, _, _), (s, sl, sh) = (tmp(slot, k) for k in range(6))
+    head = [
+        "v_pk_add_f32 %s, %s, %s op_sel_hi:[1,0] %s" % (dx, sx, xy, NEG),                 # {x0 - xi, x1 - xi}
+        "v_pk_add_f32 %s, %s, %s op_sel:[0,1] op_sel_hi:[1,1] %s" % (dy, sy, xy, NEG),    # {y0 - yi, y1 - yi}
+        "v_pk_add_f32 %s, %s, %s op_sel_hi:[1,0] %s" % (dz, sz, zz, NEG),
+        "v_pk_fma_f32 %s, %s, %s, s[%d:%d] op_sel_hi:[1,1,0]" % (r2, dz, dz, SEPS, SEPS + 1),
+        "v_pk_fma_f32 %s, %s, %s, %s" % (r2, dy, dy, r2),
+        "v_pk_fma_f32 %s, %s, %s, %s" % (r2, dx, dx, r2),
+        "v_rsq_f32_e32 %s, %s" % (r2l, r2l),
+        "v_rsq_f32_e32 %s, %s" % (r2h, r2h),
+        "v_pk_mul_f32 %s, %s, %s" % (q, r2, r2),
+        "v_pk_mul_f32 %s, %s, %s" % (s, sw, r2),                                          # {Gm0 inv0, Gm1 inv1}
+        "v_pk_mul_f32 %s, %s, %s" % (s, s, q),
+    ]
+    tail = [
+        ("v_fma_f32 %s, %s, %s, %s" % (ax, dxl, sl, ax)) if wide_first else ("v_fmac_f32_e32 %s, %s, %s" % (ax, dxl, sl)),
+        "v_fmac_f32_e32 %s, %s, %s" % (ay, dyl, sl),
+        "v_fmac_f32_e32 %s, %s, %s" % (az, dzl, sl),
+        "v_fmac_f32_e32 %s, %s, %s" % (ax, dxh, sh),
+        "v_fmac_f32_e32 %s, %s, %s" % (ay, dyh, sh),
+        "v_fmac_f32_e32 %s, %s, %s" % (az, dzh, sh),
+    ]
+    return head, tail
+
+
+def jpair_group_ops(ring, odd_tail):
+    """The 8 records (4 blocks) of one ring group on one body; odd_tail: make the group's 4-byte count odd (a lone s_waitcnt follows)."""
+    out = []
+    I = ("%3", "%4", "%0", "%1", "%2")
+    for u in range(0, 4, 2):  # two blocks in flight; block u's six updates precede block u+1's
+        ha, ta = jpair_block_ops(0, ring + 8 * u, *I, wide_first=(odd_tail and u == 2))
+        hb, tb = jpair_block_ops(1, ring + 8 * (u + 1), *I, wide_first=False)
+        out += zip2(ha, hb) + ta + tb
+    return out
+
+
+JPAIR_PREFETCH = int(os.environ.get("NBX_JPAIR_PREFETCH", "2"))  # trips ahead of the L2 prefetch (0 = none)
+VPF = TBASE + 24                                                 # destination of the prefetch load (never read)
+
+
+def jpair_loop_text(groups_per_trip):
+    assert groups_per_trip % 2 == 0 and groups_per_trip >= 2
+    trip = 128 * groups_per_trip
+    pro = ["s_mov_b64 s[%d:%d], %%5" % (SP, SP + 1),
+           "s_mov_b64 s[%d:%d], %%6" % (SE, SE + 1),
+           "s_mov_b32 s%d, 0x3a83126f" % SEPS,          # softeningSquared = 1e-3f (ver7/GSimulation.cpp:126)
+           "s_mov_b32 s%d, 0x%x" % (SEPS + 1, trip),
+           "s_nop 4"]
+    pro += loads(RING_A, trip) + [WAIT]
+    body = []
+    body += loads(RING_B, trip + 128)
+    if JPAIR_PREFETCH:
+        # L2 prefetch: a lone wave has only the 4 x 76 cycles of one ring group to cover a scalar load, and every wave of an XCD
+        # asks for the same line at about the same time, so what it waits for is the first requester's Infinity-Cache round trip
+        # (~545 cycles).  One vector load per trip, lane l touching byte 64 (l mod 16) of the trip JPAIR_PREFETCH trips ahead,
+        # pulls those 16 lines into the XCD's L2 (vmcnt is never waited on inside the loop; the destination is never read).
+        off = trip + JPAIR_PREFETCH * trip
+        assert off <= 4095 and (JPAIR_PREFETCH + 1) * (trip // 16) <= 512, "13-bit offset; reads stay inside the spare records"
+        body += ["global_load_dword v%d, %%7, s[%d:%d] offset:%d" % (VPF, SP, SP + 1, off)]
+    body += jpair_group_ops(RING_A, odd_tail=False)
+    body += [WAIT, "s_add_u32 s%d, s%d, s%d" % (SP, SP, SEPS + 1), "s_addc_u32 s%d, s%d, 0" % (SP + 1, SP + 1),
+             "s_cmp_lg_u64 s[%d:%d], s[%d:%d]" % (SP, SP + 1, SE, SE + 1)]
+    rings = (RING_A, RING_B)
+    for g in range(1, groups_per_trip):
+        nxt = g + 1
+        last = nxt == groups_per_trip
+        body += loads(rings[nxt % 2], trip if last else 128 * nxt)
+        body += jpair_group_ops(rings[g % 2], odd_tail=not last)
+        body += [WAIT, "s_cbranch_scc1 1b"] if last else [WAIT]
+    return pro, body, trip
+
+
+def emit_jpair(groups_per_trip):
+    pro, body, trip = jpair_loop_text(groups_per_trip)
+    nbytes = check_alignment(body)
+    check_distance(body)
+    post = ["s_waitcnt vmcnt(0)"] if JPAIR_PREFETCH else []  # the prefetch destination is ours until the last one has landed
+    lines = (['      "%s\\n"' % s for s in pro] + ['      ".p2align 3\\n"', '      "1:\\n"'] + ['      "%s\\n"' % s for s in body] +
+             ['      "%s\\n"' % s for s in post])
+    clob = (['"v%d"' % r for r in range(TBASE, TBASE + 24 + (1 if JPAIR_PREFETCH else 0))] + ['"s%d"' % r for r in range(28, 100) if r not in (32, 33)] +
+            ['"scc"', '"memory"'])
+    nv = sum(1 for s in body if s.startswith("v_"))
+    ns = sum(1 for s in body if not s.startswith("v_") and not s.endswith(":"))
+    txt = []
+    txt.append("// ONE body per lane, two consecutive j records per packed operation: %d records per trip, %d VALU + %d scalar%s instructions, %d bytes of loop body." %
+               (trip // 16, nv, ns - (1 if JPAIR_PREFETCH else 0), " + 1 vector-memory" if JPAIR_PREFETCH else "", nbytes))
+    txt.append("// `first` / `last` delimit the j range in the PAIR-INTERLEAVED copy of the record array ({x0 x1 y0 y1 | z0 z1 w0 w1} per two records,")
+    txt.append("// pair_transpose_kernel): same byte offsets as in the record array, a positive multiple of kSgprAsmTrip<1> records.  xy = {xi, yi}, zz = {zi, -}.")
+    txt.append("template <> constexpr int kSgprAsmTrip<1> = %d;" % (trip // 16))
+    txt.append("// pf_off = 64 * (lane mod 16): byte offset of the line this lane prefetches into L2, %d trips ahead (reads up to %d records past `last`: spare)." %
+               (JPAIR_PREFETCH, (JPAIR_PREFETCH + 1) * (trip // 16) if JPAIR_PREFETCH else 8))
+    txt.append("__device__ __forceinline__ void sgpr_loop_asm_jpair(const float4* first, const float4* last, f32x2 xy, f32x2 zz, unsigned pf_off, float& ax, float& ay, float& az) {")
+    txt.append("  const char* q = reinterpret_cast<const char*>(first) - %d;     // biased: all immediate offsets positive" % trip)
+    txt.append("  const char* qend = reinterpret_cast<const char*>(last) - %d;  // value of the pointer after the last trip's advance" % trip)
+    txt.append("  asm volatile(")
+    txt.append("\n".join(lines))
+    txt.append('      : "+v"(ax), "+v"(ay), "+v"(az)')
+    txt.append('      : "v"(xy), "v"(zz), "s"(q), "s"(qend), "v"(pf_off)')
+    txt.append("      : %s);" % ", ".join(clob))
+    txt.append("}")
+    return "\n".join(txt)
+
+
+def emit(B, groups_per_trip, ts=False, pf=False):
+    assert not (ts and pf)
+    pro, body, trip = loop_text(B, groups_per_trip, ts, pf)
     nbytes = check_alignment(body)
     check_distance(body)
     lines = ['      "%s\\n"' % s for s in pro] + ['      ".p2align 3\\n"', '      "1:\\n"'] + ['      "%s\\n"' % s for s in body]  # labels ("2:") included
-    clob = (['"v%d"' % r for r in range(TBASE, TBASE + 24)] + ['"s%d"' % r for r in range(STIME if ts else 28, 100) if r not in (32, 33)] +
+    if pf:
+        lines += ['      "s_waitcnt vmcnt(0)\\n"']  # the prefetch destination is ours until the last one has landed
+    clob = (['"v%d"' % r for r in range(TBASE, TBASE + 24 + (1 if pf else 0))] + ['"s%d"' % r for r in range(STIME if ts else 28, 100) if r not in (32, 33)] +
             ['"scc"', '"memory"'])
     nv = sum(1 for s in body if s.startswith("v_"))
     ns = sum(1 for s in body if not s.startswith("v_") and not s.endswith(":"))
@@ -200,14 +332,21 @@ def emit(B, groups_per_trip, ts=False):
         ins = '"v"(xi0), "v"(yi0), "v"(zi0), "v"(xi1), "v"(yi1), "v"(zi1), "s"(q), "s"(qend)'
         extra = ', "s"(slice_bit), "s"(slot_bit)'
     txt = []
-    txt.append("// B = %d bodies per lane%s: %d records per trip, %d VALU + %d scalar instructions, %d bytes of loop body." %
-               (B, ", time-sliced wave priority" if ts else "", trip // 16, nv, ns, nbytes))
+    txt.append("// B = %d bodies per lane%s: %d records per trip, %d VALU + %d scalar%s instructions, %d bytes of loop body." %
+               (B, ", time-sliced wave priority" if ts else (", L2 prefetch %d trips ahead" % SGPR_PREFETCH if pf else ""), trip // 16, nv, ns - (1 if pf else 0),
+                " + 1 vector-memory" if pf else "", nbytes))
     txt.append("// `first` points at the first record of the j range, `last` one past it; the range is a positive multiple of")
     txt.append("// kSgprAsmTrip<%d> records.  The final trip requests 8 records past `last` (never used; kSgprOverread spare)." % B)
     if ts:
         txt.append("// slice_bit = the clock bit (s_memrealtime, 10 ns units) that says whose turn it is; slot_bit = slice_bit when the wave's")
         txt.append("// slot on its SIMD is odd, else 0.  The wave leaves the loop at whatever priority it had last.")
         txt.append("__device__ __forceinline__ void sgpr_loop_asm_b%d_ts(const float4* first, const float4* last, unsigned slice_bit, unsigned slot_bit, %s) {" % (B, sig))
+    elif pf:
+        txt.append("// For launches that leave ONE wave per SIMD (e.g. a rank that owns 131072 of 1M bodies): the arithmetic of one ring group is all the")
+        txt.append("// cover a scalar load gets, and what it waits for is an Infinity-Cache round trip; with the lines already in L2 the loop is +3.5 %.")
+        txt.append("// With two or more waves per SIMD the other waves are the cover and the extra instruction costs 0.4-1.4 % (profiles/r04_b2_prefetch_ab.txt).")
+        txt.append("__device__ __forceinline__ void sgpr_loop_asm_b%d_pf(const float4* first, const float4* last, %s) {" % (B, sig))
+        txt.append("  const unsigned pf_off = (threadIdx.x & 15u) * 64u;  // the line this lane touches: reads up to %d records past `last` (spare)" % ((SGPR_PREFETCH + 1) * (trip // 16)))
     else:
         txt.append("template <> constexpr int kSgprAsmTrip<%d> = %d;" % (B, trip // 16))
         txt.append("__device__ __forceinline__ void sgpr_loop_asm_b%d(const float4* first, const float4* last, %s) {" % (B, sig))
@@ -216,7 +355,7 @@ def emit(B, groups_per_trip, ts=False):
     txt.append("  asm volatile(")
     txt.append("\n".join(lines))
     txt.append("      : %s" % outs)
-    txt.append("      : %s%s" % (ins, extra if ts else ""))
+    txt.append("      : %s%s%s" % (ins, extra if ts else "", ', "v"(pf_off)' if pf else ""))
     txt.append("      : %s);" % ", ".join(clob))
     txt.append("}")
     return "\n".join(txt)
@@ -228,7 +367,7 @@ def main():
     parts = ["// nbx_sgpr_loop.inc -- GENERATED by tools/gen_sgpr_loop.py (see its docstring for the why); do not edit.",
              "// Included by nbx_kernels.hpp inside namespace nbx.  tests/test_isa_audit.py checks it is in sync with the generator.",
              "template <int B> constexpr int kSgprAsmTrip = 0;",
-             emit(2, 8), emit(4, 4), emit(2, 8, ts=True), emit(4, 4, ts=True), ""]
+             emit(2, 8), emit(4, 4), emit(2, 8, ts=True), emit(4, 4, ts=True), emit(2, 8, pf=True), emit(4, 4, pf=True), emit_jpair(JPAIR_GROUPS), ""]
     open(out, "w").write("\n".join(parts))
 
 
