@@ -100,11 +100,17 @@ typedef struct nbx_opts {
                                   with the reference within the 1e-4 gate: 2e-5 over 500 steps at n = 131072) and for fp64
                                   (its summation noise is ~1e-13, far inside the 1e-10 gate either way) */
   int32_t inner_loop;      /* scheduling of the SGPR kernel's j loop: 0 = NBX_LOOP_AUTO (the hand-scheduled gfx950 loop wherever
-                              an instance exists: packed fp32, kernel_variant SGPR or SGPRW, 2 or 4 bodies per lane, whole trips per wave), 1 = NBX_LOOP_CXX
+                              an instance exists: fp32, kernel_variant SGPR or SGPRW, 2 or 4 bodies per lane, whole trips per wave; with
+                              kernel_variant SGPR and ONE body per lane it is the two-j-records-per-packed-operation loop -- what AUTO
+                              takes for reference-order slices of up to 256 x CUs bodies, which leave less than one wave per SIMD
+                              at two bodies per lane: 46.7 % of the roofline for 65536 of 262144 bodies against 28.3 %), 1 = NBX_LOOP_CXX
                               (always the compiler-scheduled C++ loop), 2 = NBX_LOOP_ASM (fail if no instance fits the shape),
                               3 = NBX_LOOP_ASM_TS (the hand-scheduled loop with time-sliced wave priority: the waves sharing a SIMD
                               take turns as the favoured one instead of running one after the other; single-row SGPR kernel only --
-                              AUTO takes it there when the fullest CU holds exactly two workgroups, where it measured +3 ... +4.5 %).  All loops perform the same operations in
+                              AUTO takes it there when the fullest CU holds exactly two workgroups, where it measured +3 ... +4.5 %),
+                              4 = NBX_LOOP_ASM_PF (the hand-scheduled loop plus one L2-prefetch load per trip; same kernel scope as
+                              ASM_TS; AUTO takes it when the launch leaves one wave per SIMD -- a rank that owns 131072 of 1M
+                              bodies, +3.5 % -- and never with more).  All loops perform the same operations in
                               the same order: results are bit-identical */
   int32_t reserved[2];
 } nbx_opts;
@@ -123,7 +129,7 @@ typedef struct nbx_stats_t {
   char    device_name[64];
   int64_t graph_replays;       /* hipGraph launches issued by nbx_step (each covers up to 50 steps) */
   int32_t use_graph;           /* 1 if nbx_step replays windows from a hipGraph */
-  int32_t inner_loop;          /* NBX_LOOP_CXX, NBX_LOOP_ASM or NBX_LOOP_ASM_TS actually in use by the step kernel */
+  int32_t inner_loop;          /* NBX_LOOP_CXX, NBX_LOOP_ASM, NBX_LOOP_ASM_TS or NBX_LOOP_ASM_PF actually in use by the step kernel */
 } nbx_stats_t;
 
 /* Text of the last error on the calling thread ("" if none). Never NULL. */
@@ -224,6 +230,34 @@ int nbx_group_info(nbx_group* g, int32_t* n_ranks, int32_t* uses_rccl, int32_t r
  */
 int nbx_partition(int32_t n, int32_t n_ranks, int32_t rank, int32_t* ranks_used, int32_t* block, int32_t* i_begin,
                   int32_t* i_count, int32_t* n_alloc);
+
+/*
+ * Unequal shares -- the GPU-native reading of the reference's co-execution split (ver5_all/main.cpp:40-54 feeds `cpu_ratio` to
+ * opencl/Compute.cpp:154-162: a fixed ratio, or "tuning" when it is negative; :241-255 turns it into per-device shares and offsets;
+ * :317-321 steps it every print window).  There the two devices are a CPU and a GPU; here they are GPUs that hold clocks up to 10 %
+ * apart under this load (one binary: 0.553 ... 0.609 of the roofline over the boxes of the pool), and with equal blocks the slowest
+ * device sets every step.
+ *   nbx_partition_weighted   : the ceil(n / 256) tiles of 256 records handed out in proportion to `weights` (largest remainder,
+ *                              every rank at least one tile; weights NULL = equal).  All ranks hold n_alloc = 256 * tiles records.
+ *   nbx_group_create_weighted: nbx_group_create with that partition (single process, k GPUs).  The per-step exchange becomes one
+ *                              in-place ncclBroadcast per owner (grouped), or the same peer copies as before; every context times
+ *                              its force launches (HIP events), which is what the tuner weighs the devices by.
+ *   nbx_group_shares         : who owns what right now, and each rank's mean force-kernel time since the last retune (ms; 0 = none).
+ *   nbx_tune_weights         : host arithmetic of the tuner: weight_r = i_count_r / force_ms_r, normalised -- every rank's measured
+ *                              rate.  Fed back into nbx_partition_weighted the ranks' times meet within one tile.
+ *   nbx_group_retune         : measure (force_ms == NULL) or take the caller's per-rank times, compute new shares and, if any
+ *                              boundary moves, carry the state over to contexts with the new slices (once through the host;
+ *                              values are copied, never recomputed: in reference summation order the trajectory is the same bit
+ *                              for bit whoever owns a body).  *changed = 1 if the shares moved.  Call it between windows, e.g.
+ *                              after every nbx_group_step that asked for the energy (nbody.x: every printed row, like the reference).
+ */
+int nbx_partition_weighted(int32_t n, int32_t n_ranks, const double* weights, int32_t rank, int32_t* ranks_used, int32_t* i_begin,
+                           int32_t* i_count, int32_t* n_alloc);
+int nbx_group_create_weighted(nbx_group** out, int32_t n, int32_t precision, int32_t n_ranks, const int32_t* devices,
+                              const double* weights, const nbx_opts* opts);
+int nbx_group_shares(nbx_group* g, int32_t* i_begin /* [ranks] */, int32_t* i_count /* [ranks] */, double* force_ms /* [ranks] */);
+int nbx_tune_weights(int32_t n_ranks, const int32_t* i_count, const double* force_ms, double* weights_out);
+int nbx_group_retune(nbx_group* g, const double* force_ms /* [ranks] or NULL = measured */, int32_t* changed);
 
 /*
  * One process per GPU (the reference's MPI mode: init_mpi + mpi_bcast_all + mpi_gather_acc,

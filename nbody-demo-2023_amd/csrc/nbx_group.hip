@@ -45,6 +45,7 @@ struct Rccl {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;  // weighted groups: blocks of unequal size, one broadcast per owner
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool ok = false;
   template <typename F> static void sym(void* h, const char* name, F& fn) { fn = reinterpret_cast<F>(dlsym(h, name)); }
@@ -60,8 +61,9 @@ struct Rccl {
     sym(h, "ncclGroupStart", GroupStart);
     sym(h, "ncclGroupEnd", GroupEnd);
     sym(h, "ncclAllGather", AllGather);
+    sym(h, "ncclBroadcast", Broadcast);
     sym(h, "ncclGetErrorString", GetErrorString);
-    ok = CommInitAll && CommInitRank && GetUniqueId && CommDestroy && GroupStart && GroupEnd && AllGather;
+    ok = CommInitAll && CommInitRank && GetUniqueId && CommDestroy && GroupStart && GroupEnd && AllGather && Broadcast;
     return ok;
   }
   std::string text(ncclResult_t e) const { return GetErrorString ? std::string(GetErrorString(e)) : std::string("RCCL error ") + std::to_string((int)e); }
@@ -88,6 +90,15 @@ struct nbx_group {
   // watchdog bookkeeping (nbx_watchdog.hpp): steps enqueued since the last host synchronisation, and what one step took
   long long steps_unsynced = 0;
   double step_s_est = 0.0;           // seconds per step measured over the last fully synchronised nbx_group_step call; 0 = not yet
+  // weighted groups (nbx_group_create_weighted): rank r owns [begin[r], begin[r] + count[r]), whole 256-record tiles in proportion
+  // to its weight; the per-step exchange is one broadcast per owner instead of the equal-block all-gather
+  bool weighted = false;
+  std::vector<int> begin, count;
+  std::vector<double> weight;
+  nbx_opts opts{};                   // launch-shape options the contexts were made with (nbx_group_retune rebuilds them)
+  std::vector<char> mass_host;       // the masses as uploaded (n elements of the group's precision): needed to re-upload after a retune
+  bool uploaded = false;
+  long long retunes = 0;
 };
 
 namespace {
@@ -103,6 +114,51 @@ void partition(int n, int n_ranks, int* P_out, int* block_out) {
   }
   *P_out = P;
   *block_out = block;
+}
+
+// Weighted partition: the ceil(n / 256) tiles of 256 records are handed out in proportion to the weights (largest remainder, ties to
+// the lower rank), every rank at least one tile; ranks beyond the number of tiles are dropped.  The reference's co-execution split
+// gives device 0 `n * cpu_ratio` bodies and the rest to the other device (opencl/Compute.cpp:241-249); here every block stays a whole
+// number of j tiles, which is what the kernels' zero-mass padding and the in-place exchange rely on.
+int partition_weighted(int n, int n_ranks, const double* w, std::vector<int>* begin, std::vector<int>* count, int* n_alloc) {
+  const int tiles = ceil_div(n, kTile);
+  const int P = std::min(n_ranks, tiles);
+  double sum = 0.0;
+  for (int r = 0; r < P; ++r) {
+    const double x = w ? w[r] : 1.0;
+    if (!(x > 0.0) || !std::isfinite(x)) return fail(NBX_ERR_ARG, "weights must be finite and > 0");
+    sum += x;
+  }
+  std::vector<double> ideal((size_t)P);
+  std::vector<int> t((size_t)P);
+  long long total = 0;
+  for (int r = 0; r < P; ++r) {
+    ideal[r] = (double)tiles * (w ? w[r] : 1.0) / sum;
+    t[r] = std::max(1, (int)std::floor(ideal[r]));
+    total += t[r];
+  }
+  while (total != tiles) {  // at most P passes each way: every rank is within one tile of its ideal share afterwards (or at the 1-tile floor)
+    int pick = -1;
+    double best = 0.0;
+    for (int r = 0; r < P; ++r) {
+      const double d = total < tiles ? ideal[r] - t[r] : t[r] - ideal[r];
+      if (total > tiles && t[r] <= 1) continue;
+      if (pick < 0 || d > best) { pick = r; best = d; }
+    }
+    if (pick < 0) return fail(NBX_ERR_STATE, "partition_weighted: cannot balance the tiles");  // cannot happen: P <= tiles
+    t[pick] += total < tiles ? 1 : -1;
+    total += total < tiles ? 1 : -1;
+  }
+  begin->assign((size_t)P, 0);
+  count->assign((size_t)P, 0);
+  int first = 0;
+  for (int r = 0; r < P; ++r) {
+    (*begin)[r] = first * kTile;
+    (*count)[r] = std::min(n, (first + t[r]) * kTile) - first * kTile;
+    first += t[r];
+  }
+  *n_alloc = tiles * kTile;
+  return NBX_OK;
 }
 
 // Seconds of legitimately queued work in front of a synchronisation: the watchdog's deadline is its timeout PLUS this, so
@@ -122,6 +178,26 @@ int rccl_fail(const char* what, ncclResult_t e) { return fail(NBX_ERR_DEVICE, st
 
 int group_exchange(nbx_group* g) {
   const size_t rec = g->rank[0]->rec;
+  if (g->use_rccl && g->weighted) {
+    // blocks of unequal size: one in-place broadcast per owner, all of them in one group (single-process groups only)
+    ncclResult_t e = g_rccl.GroupStart();
+    if (e != ncclSuccess) return rccl_fail("ncclGroupStart", e);
+    int rc = NBX_OK;
+    for (size_t k = 0; k < g->rank.size() && rc == NBX_OK; ++k) {
+      nbx_ctx* c = g->rank[k];
+      char* buf = (char*)c->posm[c->cur ^ 1];
+      const hipError_t he = hipSetDevice(g->dev[k]);
+      if (he != hipSuccess) { rc = fail(NBX_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(he)); break; }
+      for (int r = 0; r < g->P && rc == NBX_OK; ++r) {
+        char* blk = buf + (size_t)g->begin[r] * rec;
+        e = g_rccl.Broadcast(blk, blk, (size_t)g->count[r] * rec, ncclChar, r, g->comm[k], c->stream);
+        if (e != ncclSuccess) rc = rccl_fail("ncclBroadcast", e);
+      }
+    }
+    e = g_rccl.GroupEnd();
+    if (rc == NBX_OK && e != ncclSuccess) rc = rccl_fail("ncclGroupEnd", e);
+    return rc;
+  }
   if (g->use_rccl) {
     // in place: rank r sends its own block, receives every block at its natural offset.  Once the group is open every
     // path reaches ncclGroupEnd: an early return would leave RCCL in group mode for the rest of the process.
@@ -199,38 +275,66 @@ int nbx_partition(int32_t n, int32_t n_ranks, int32_t rank, int32_t* ranks_used,
   });
 }
 
-int nbx_group_create(nbx_group** out, int32_t n, int32_t precision, int32_t n_ranks, const int32_t* devices,
-                     const nbx_opts* opts) {
-  return guarded("nbx_group_create", [&]() -> int {
+}  // extern "C"
+
+namespace {
+
+// (re)creates the contexts of a single-process group from g->begin / g->count
+int make_contexts(nbx_group* g, const char* who) {
+  for (nbx_ctx* c : g->rank) nbx_destroy(c);
+  g->rank.clear();
+  nbx_opts o = g->opts;
+  for (int r = 0; r < g->P; ++r) {
+    o.device = g->dev[r];
+    o.i_begin = g->begin[r];
+    o.i_count = g->count[r];
+    o.n_alloc = g->n_alloc;
+    nbx_ctx* c = nullptr;
+    const int rc = nbx_create(&c, g->n, g->precision, &o);
+    if (rc != NBX_OK) { const std::string m = last_error(); return fail(rc, std::string(who) + ": rank " + std::to_string(r) + ": " + m); }
+    g->rank.push_back(c);
+    if (g->weighted) {  // per-launch timing of the force kernel: what nbx_group_retune weighs the ranks by
+      const int pc = nbx_profile(c, 1);
+      if (pc != NBX_OK) return pc;
+    }
+  }
+  return NBX_OK;
+}
+
+int create_single_process(const char* who, nbx_group** out, int32_t n, int32_t precision, int32_t n_ranks, const int32_t* devices,
+                          bool weighted, const double* weights, const nbx_opts* opts) {
   nbx_opts o;
-  int rc = check_group_args("nbx_group_create", out, n, precision, n_ranks, opts, &o);
+  int rc = check_group_args(who, out, n, precision, n_ranks, opts, &o);
   if (rc) return rc;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(NBX_ERR_DEVICE, "nbx_group_create: no HIP device available (libnbx has no CPU path)");
-  int P = 0, block = 0;
-  partition(n, n_ranks, &P, &block);
+    return fail(NBX_ERR_DEVICE, std::string(who) + ": no HIP device available (libnbx has no CPU path)");
   nbx_group* g = new (std::nothrow) nbx_group();
-  if (!g) return fail(NBX_ERR_ALLOC, "nbx_group_create: out of host memory");
+  if (!g) return fail(NBX_ERR_ALLOC, std::string(who) + ": out of host memory");
   struct Owner { nbx_group* g; ~Owner() { nbx_group_destroy(g); } } owner{g};  // every failure path below frees the group
-  g->n = n; g->precision = precision; g->P = P; g->block = block; g->n_alloc = P * block;
+  g->n = n; g->precision = precision; g->opts = o; g->weighted = weighted;
+  if (weighted) {
+    rc = partition_weighted(n, n_ranks, weights, &g->begin, &g->count, &g->n_alloc);
+    if (rc) { const std::string m = last_error(); return fail(rc, std::string(who) + ": " + m); }
+    g->P = (int)g->begin.size();
+    g->block = 0;  // no common block size
+    for (int r = 0; r < g->P; ++r) g->weight.push_back(weights ? weights[r] : 1.0);
+  } else {
+    int P = 0, block = 0;
+    partition(n, n_ranks, &P, &block);
+    g->P = P; g->block = block; g->n_alloc = P * block;
+    for (int r = 0; r < P; ++r) { g->begin.push_back(r * block); g->count.push_back(std::min(n, (r + 1) * block) - r * block); }
+  }
+  const int P = g->P;
   bool distinct = true;
   for (int r = 0; r < P; ++r) {
     const int d = devices ? devices[r] : r % ndev;
-    if (d < 0 || d >= ndev) return fail(NBX_ERR_ARG, "nbx_group_create: device ordinal out of range");
+    if (d < 0 || d >= ndev) return fail(NBX_ERR_ARG, std::string(who) + ": device ordinal out of range");
     for (int q : g->dev) distinct = distinct && q != d;
     g->dev.push_back(d);
   }
-  for (int r = 0; r < P; ++r) {
-    o.device = g->dev[r];
-    o.i_begin = r * block;
-    o.i_count = std::min(n, (r + 1) * block) - r * block;
-    o.n_alloc = g->n_alloc;
-    nbx_ctx* c = nullptr;
-    rc = nbx_create(&c, n, precision, &o);
-    if (rc != NBX_OK) { const std::string m = last_error(); return fail(rc, "nbx_group_create: rank " + std::to_string(r) + ": " + m); }
-    g->rank.push_back(c);
-  }
+  rc = make_contexts(g, who);
+  if (rc) return rc;
   const char* force = std::getenv("NBX_EXCHANGE");  // "copy" forces the peer-copy path, "rccl" insists on RCCL
   const bool insist = force && !std::strcmp(force, "rccl");  // also with a single rank: smoke-tests the RCCL binding
   const bool want_rccl = distinct && (P > 1 || insist) && !(force && !std::strcmp(force, "copy"));
@@ -241,12 +345,12 @@ int nbx_group_create(nbx_group** out, int32_t n, int32_t precision, int32_t n_ra
     else g->comm.clear();
   }
   if (insist && !g->use_rccl)
-    return fail(NBX_ERR_DEVICE, "nbx_group_create: NBX_EXCHANGE=rccl but RCCL is unavailable for these devices");
+    return fail(NBX_ERR_DEVICE, std::string(who) + ": NBX_EXCHANGE=rccl but RCCL is unavailable for these devices");
   if (!g->use_rccl) {
     g->done.assign(P, nullptr);
     for (int r = 0; r < P; ++r) {
       if (hipSetDevice(g->dev[r]) != hipSuccess || hipEventCreateWithFlags(&g->done[r], hipEventDisableTiming) != hipSuccess)
-        return fail(NBX_ERR_DEVICE, "nbx_group_create: hipEventCreate failed");
+        return fail(NBX_ERR_DEVICE, std::string(who) + ": hipEventCreate failed");
       for (int q = 0; q < P; ++q)  // best effort: direct peer access speeds hipMemcpyPeerAsync up
         if (g->dev[q] != g->dev[r]) { (void)hipDeviceEnablePeerAccess(g->dev[q], 0); (void)hipGetLastError(); }
     }
@@ -254,6 +358,131 @@ int nbx_group_create(nbx_group** out, int32_t n, int32_t precision, int32_t n_ra
   owner.g = nullptr;
   *out = g;
   last_error().clear();
+  return NBX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nbx_group_create(nbx_group** out, int32_t n, int32_t precision, int32_t n_ranks, const int32_t* devices,
+                     const nbx_opts* opts) {
+  return guarded("nbx_group_create", [&]() -> int {
+    return create_single_process("nbx_group_create", out, n, precision, n_ranks, devices, false, nullptr, opts);
+  });
+}
+
+int nbx_group_create_weighted(nbx_group** out, int32_t n, int32_t precision, int32_t n_ranks, const int32_t* devices,
+                              const double* weights, const nbx_opts* opts) {
+  return guarded("nbx_group_create_weighted", [&]() -> int {
+    return create_single_process("nbx_group_create_weighted", out, n, precision, n_ranks, devices, true, weights, opts);
+  });
+}
+
+int nbx_partition_weighted(int32_t n, int32_t n_ranks, const double* weights, int32_t rank, int32_t* ranks_used, int32_t* i_begin,
+                           int32_t* i_count, int32_t* n_alloc) {
+  return guarded("nbx_partition_weighted", [&]() -> int {
+  if (n <= 0 || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(NBX_ERR_ARG, "nbx_partition_weighted: need n > 0 and 0 <= rank < n_ranks");
+  std::vector<int> b, c;
+  int na = 0;
+  const int rc = partition_weighted(n, n_ranks, weights, &b, &c, &na);
+  if (rc) { const std::string m = last_error(); return fail(rc, "nbx_partition_weighted: " + m); }
+  const int P = (int)b.size();
+  if (ranks_used) *ranks_used = P;
+  if (i_begin) *i_begin = rank < P ? b[rank] : n;
+  if (i_count) *i_count = rank < P ? c[rank] : 0;
+  if (n_alloc) *n_alloc = na;
+  return NBX_OK;
+  });
+}
+
+// New weights from what every rank achieved: its bodies per millisecond of force kernel, normalised to sum 1.
+int nbx_tune_weights(int32_t n_ranks, const int32_t* i_count, const double* force_ms, double* weights_out) {
+  return guarded("nbx_tune_weights", [&]() -> int {
+  if (n_ranks <= 0 || !i_count || !force_ms || !weights_out) return fail(NBX_ERR_ARG, "nbx_tune_weights: NULL argument or no ranks");
+  double sum = 0.0;
+  for (int r = 0; r < n_ranks; ++r) {
+    if (i_count[r] <= 0 || !(force_ms[r] > 0.0) || !std::isfinite(force_ms[r]))
+      return fail(NBX_ERR_ARG, "nbx_tune_weights: every rank needs bodies and a positive measured time");
+    sum += (double)i_count[r] / force_ms[r];
+  }
+  for (int r = 0; r < n_ranks; ++r) weights_out[r] = ((double)i_count[r] / force_ms[r]) / sum;
+  return NBX_OK;
+  });
+}
+
+int nbx_group_shares(nbx_group* g, int32_t* i_begin, int32_t* i_count, double* force_ms) {
+  return guarded("nbx_group_shares", [&]() -> int {
+  if (!g) return fail(NBX_ERR_ARG, "nbx_group_shares: group is NULL");
+  for (int r = 0; r < g->P; ++r) {
+    if (i_begin) i_begin[r] = g->begin[r];
+    if (i_count) i_count[r] = g->count[r];
+  }
+  if (force_ms) {
+    for (int r = 0; r < g->P; ++r) force_ms[r] = 0.0;
+    for (size_t k = 0; k < g->rank.size(); ++k) {
+      nbx_stats_t st;
+      const int rc = nbx_stats(g->rank[k], &st);  // synchronises this rank's stream and drains its events
+      if (rc) return rc;
+      const int r = g->my_rank >= 0 ? g->my_rank : (int)k;
+      force_ms[r] = st.force_launches_timed > 0 ? st.force_ms_total / (double)st.force_launches_timed : 0.0;
+    }
+  }
+  return NBX_OK;
+  });
+}
+
+int nbx_group_retune(nbx_group* g, const double* force_ms, int32_t* changed) {
+  return guarded("nbx_group_retune", [&]() -> int {
+  if (changed) *changed = 0;
+  if (!g) return fail(NBX_ERR_ARG, "nbx_group_retune: group is NULL");
+  if (!g->weighted || g->my_rank >= 0) return fail(NBX_ERR_STATE, "nbx_group_retune: needs a single-process group made by nbx_group_create_weighted");
+  if (!g->uploaded) return fail(NBX_ERR_STATE, "nbx_group_retune: nbx_group_upload has not been called");
+  std::vector<double> ms((size_t)g->P), w((size_t)g->P);
+  if (force_ms) {
+    for (int r = 0; r < g->P; ++r) ms[r] = force_ms[r];
+  } else {
+    const int rc = nbx_group_shares(g, nullptr, nullptr, ms.data());
+    if (rc) return rc;
+    for (int r = 0; r < g->P; ++r)
+      if (!(ms[r] > 0.0)) return NBX_OK;  // a rank without a timed launch since the last retune: nothing to weigh by, shares stay
+  }
+  int rc = nbx_tune_weights(g->P, g->count.data(), ms.data(), w.data());
+  if (rc) return rc;
+  std::vector<int> b, c;
+  int na = 0;
+  rc = partition_weighted(g->n, g->P, w.data(), &b, &c, &na);
+  if (rc) return rc;
+  // restart the measurement window whether or not the shares move
+  auto restart_timing = [&]() -> int {
+    for (nbx_ctx* x : g->rank) {
+      int pc = nbx_profile(x, 0);
+      if (pc == NBX_OK) pc = nbx_profile(x, 1);
+      if (pc != NBX_OK) return pc;
+    }
+    return NBX_OK;
+  };
+  if ((int)b.size() != g->P || na != g->n_alloc || c == g->count) return restart_timing();  // same shares (or the 256-record tiles allow no finer step)
+  // Shares move: velocities live with their owners, so the state goes through the host once -- positions from rank 0 (every rank holds
+  // them all), velocities from each owner -- and comes back to contexts with the new slices.  Values are copied, never recomputed: the
+  // trajectory is the same bit for bit in reference summation order, whoever owns a body (tests compare).
+  const size_t es = g->precision == 32 ? sizeof(float) : sizeof(double);
+  std::vector<char> h(6 * es * (size_t)g->n);
+  char* a[6];
+  for (int k = 0; k < 6; ++k) a[k] = h.data() + (size_t)k * es * (size_t)g->n;
+  rc = nbx_group_download(g, a[0], a[1], a[2], a[3], a[4], a[5]);
+  if (rc) return rc;
+  g->begin = b; g->count = c; g->weight = w;
+  rc = make_contexts(g, "nbx_group_retune");
+  if (rc) return rc;
+  for (nbx_ctx* x : g->rank) {
+    rc = nbx_upload(x, a[0], a[1], a[2], a[3], a[4], a[5], g->mass_host.data());
+    if (rc) return rc;
+  }
+  g->steps_unsynced = 0;
+  g->step_s_est = 0.0;
+  g->retunes += 1;
+  if (changed) *changed = 1;
   return NBX_OK;
   });
 }
@@ -354,6 +583,11 @@ int nbx_group_upload(nbx_group* g, const void* px, const void* py, const void* p
     const int rc = nbx_upload(c, px, py, pz, vx, vy, vz, m);
     if (rc) return rc;
   }
+  if (g->weighted && m) {  // nbx_group_retune re-uploads the state to contexts with other slices: it needs the masses again
+    const size_t bytes = (g->precision == 32 ? sizeof(float) : sizeof(double)) * (size_t)g->n;
+    g->mass_host.assign((const char*)m, (const char*)m + bytes);
+  }
+  g->uploaded = true;
   return NBX_OK;
   });
 }

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <iomanip>
 #include <iostream>
+#include <string>
 #include <vector>
 
 #include "../../include/nbx.h"
@@ -108,7 +109,7 @@ void GSimulation::read_world_env() {
   const char* p = std::getenv("NBODY_MASTER_PORT");
   if (!p && torchrun) p = std::getenv("MASTER_PORT");
   if (p && *p) _master_port = std::atoi(p);
-  _local_rank = env_int("NBODY_LOCAL_RANK", (torchrun || _multiprocess) ? env_int("LOCAL_RANK", -1) : -1);
+  _local_rank = env_int("NBODY_LOCAL_RANK", torchrun ? env_int("LOCAL_RANK", -1) : -1);  // the generic LOCAL_RANK only under the opt-in
 }
 
 void GSimulation::require_world() const {
@@ -208,15 +209,18 @@ void GSimulation::start() {
 
   // ver5_all device word (ver5_all/main.cpp:40-47): 1 = "cpu", 2 = "gpu", 3 = "cpu+gpu", 0 = not given.  libnbx has no
   // CPU engine by design (no fallback may stand in for the HIP path), so "cpu" is refused here -- also when the
-  // reference's own main.cpp drives this class -- and "cpu+gpu" runs every body on the GPU: the co-execution split of
-  // the OpenCL back end (cpu_ratio, opencl/Compute.cpp:154-162,241-255) is a non-goal, see INTEGRATION.md.
+  // reference's own main.cpp drives this class.  "cpu+gpu" is the co-execution split of the OpenCL back end: two devices share
+  // the bodies by `cpu_ratio` (argv[4]; opencl/Compute.cpp:154-162,241-255), and a negative ratio means "tuning": the ratio is
+  // stepped every print window (:317-321).  Its GPU-native reading (include/nbx.h, nbx_group_create_weighted): every device is a
+  // GPU; with NBODY_GPUS=k >= 2 device 0 owns the share `cpu_ratio` and the other devices split the rest (exactly the reference's
+  // arithmetic for two devices), and a negative or missing ratio tunes -- every printed row the shares are re-weighted from each
+  // device's measured force-kernel time.  With a single GPU there is nothing to split: all bodies run there and the note below goes
+  // to stderr, to the `#` lines behind the footer and to NBODY_JSON.
   if (_devices == 1) {
     std::cerr << "nbody.x: device \"cpu\" requested, but this build has no CPU engine (the hot path lives in libnbx on the GPU); use gpu"
               << std::endl;
     std::exit(1);
   }
-  if (_devices == 3 && world_rank == 0)
-    std::cerr << "nbody.x: cpu+gpu co-execution is not implemented; all bodies run on the GPU (cpu_ratio ignored)" << std::endl;
   const bool root = world_rank == 0;  // every rank computes; rank 0 alone prints (ver5_all/GSimulation.cpp:119,136,162)
 
   init();
@@ -271,6 +275,7 @@ void GSimulation::start() {
   if (const char* lp = std::getenv("NBODY_LOOP")) {
     if (!std::strcmp(lp, "asm")) opts.inner_loop = NBX_LOOP_ASM;
     if (!std::strcmp(lp, "asm_ts")) opts.inner_loop = NBX_LOOP_ASM_TS;
+    if (!std::strcmp(lp, "asm_pf")) opts.inner_loop = NBX_LOOP_ASM_PF;
     if (!std::strcmp(lp, "cxx")) opts.inner_loop = NBX_LOOP_CXX;
   }
   // NBODY_ORDER=reference|tree: how each body's pair terms are summed (include/nbx.h summation_order); default auto
@@ -282,6 +287,42 @@ void GSimulation::start() {
   // NBODY_GPUS=k: block-partition the bodies over k GPUs of this node (one all-gather of positions per step);
   // k larger than the device count gives logical ranks sharing devices.  Default: one context on one GPU.
   const int gpus = env_int("NBODY_GPUS", 1);
+  // Unequal shares (single process, k >= 2): NBODY_WEIGHTS=w0,w1,... fixes them, NBODY_TUNE=1 re-weights them every printed row from
+  // the measured force-kernel times; the ver5_all device word cpu+gpu maps onto the same two things (see above).
+  std::vector<double> weights;
+  bool tune = env_int("NBODY_TUNE", 0) != 0;
+  if (const char* ws = std::getenv("NBODY_WEIGHTS")) {
+    const char* q = ws;
+    while (*q) {
+      char* end = NULL;
+      const double v = std::strtod(q, &end);
+      if (end == q) break;
+      weights.push_back(v);
+      q = (*end == ',') ? end + 1 : end;
+    }
+    if ((int)weights.size() != gpus) {
+      std::cerr << "nbody.x: NBODY_WEIGHTS needs " << gpus << " comma-separated numbers (NBODY_GPUS=" << gpus << "), got " << weights.size() << std::endl;
+      std::exit(1);
+    }
+  }
+  std::string split_note;  // what became of cpu+gpu / cpu_ratio: stderr, the `#` lines behind the footer, NBODY_JSON
+  if (_devices == 3) {
+    if (_multiprocess || gpus < 2) {
+      split_note = _multiprocess ? "cpu+gpu: one process per GPU uses equal blocks, cpu_ratio ignored (unequal shares need the single-process form, NBODY_GPUS=k)"
+                                 : "cpu+gpu: one GPU and no CPU engine, all bodies on the GPU, cpu_ratio ignored (NBODY_GPUS=k >= 2 splits by it)";
+    } else if (weights.empty()) {
+      if (_cpu_ratio > 0.f && _cpu_ratio < 1.f) {
+        weights.assign((size_t)gpus, (1.0 - (double)_cpu_ratio) / (double)(gpus - 1));
+        weights[0] = (double)_cpu_ratio;
+        split_note = "cpu+gpu: device 0 owns the share cpu_ratio = " + std::to_string(_cpu_ratio) + ", the other " + std::to_string(gpus - 1) + " device(s) the rest";
+      } else {
+        tune = true;  // negative (the reference's tuning mode), missing, or a ratio that would leave a device without bodies
+        split_note = "cpu+gpu: tuning -- shares re-weighted every printed row from each device's measured force-kernel time";
+      }
+    }
+    if (root && !split_note.empty()) std::cerr << "nbody.x: " << split_note << std::endl;
+  }
+  const bool weighted = !_multiprocess && gpus >= 2 && (tune || !weights.empty());
   nbx_ctx* ctx = NULL;
   nbx_group* grp = NULL;
   if (_multiprocess) {
@@ -300,7 +341,16 @@ void GSimulation::start() {
     // a rank whose peer died after the rendezvous ends with status NBX_EXIT_COLLECTIVE_TIMEOUT instead of hanging in
     // ncclCommInitRank or in a window's synchronisation (the reference's MPI mode hangs: ver5_all/GSimulation.cpp:170-214)
     if (const char* ct = std::getenv("NBODY_COLLECTIVE_TIMEOUT")) {
-      if (*ct && nbx_collective_timeout(std::atof(ct))) die_nbx("nbx_collective_timeout");
+      if (*ct) {  // a number of seconds, 0 = off; anything unparsable is refused: "off" read as 0.0 used to switch the bound off silently
+        char* end = NULL;
+        const double v = std::strtod(ct, &end);
+        while (end && (*end == ' ' || *end == '\t')) ++end;
+        if (end == ct || (end && *end)) {
+          std::cerr << "nbody.x: NBODY_COLLECTIVE_TIMEOUT=\"" << ct << "\" is not a number of seconds (0 switches the bound off)" << std::endl;
+          std::exit(1);
+        }
+        if (nbx_collective_timeout(v)) die_nbx("nbx_collective_timeout");
+      }
     }
     char token[NBX_UNIQUE_ID_BYTES];
     std::memset(token, 0, sizeof token);
@@ -315,6 +365,11 @@ void GSimulation::start() {
     }
     const int dev = opts.device >= 0 ? opts.device : _local_rank;  // NBODY_DEVICE, else LOCAL_RANK, else rank % device count
     if (nbx_group_create_rank(&grp, n, kPrecisionBits, world_size, world_rank, token, dev, &opts)) die_nbx("nbx_group_create_rank");
+    if (nbx_group_upload(grp, particles->pos_x, particles->pos_y, particles->pos_z, particles->vel_x, particles->vel_y,
+                         particles->vel_z, particles->mass))
+      die_nbx("nbx_group_upload");
+  } else if (weighted) {
+    if (nbx_group_create_weighted(&grp, n, kPrecisionBits, gpus, NULL, weights.empty() ? NULL : weights.data(), &opts)) die_nbx("nbx_group_create_weighted");
     if (nbx_group_upload(grp, particles->pos_x, particles->pos_y, particles->pos_z, particles->vel_x, particles->vel_y,
                          particles->vel_z, particles->mass))
       die_nbx("nbx_group_upload");
@@ -337,6 +392,7 @@ void GSimulation::start() {
   int nf = 0;
   struct Window { int step; double kenergy, seconds; };
   std::vector<Window> windows;  // for NBODY_JSON: every printed row at full precision
+  int retunes = 0;              // windows after which the tuner moved the shares
 
   CPUTime time;
   const double t0 = time.start();
@@ -360,6 +416,17 @@ void GSimulation::start() {
     nf += 1;
     const double wt = w1 - w0;
     windows.push_back(Window{done, ke, wt});
+    if (weighted && tune) {
+      // the reference prints its ratio in front of every row of a tuning run (opencl/Compute.cpp:317-319) and then steps it by 0.01;
+      // here the line shows device 0's share of the window just timed, and the next window runs on shares re-weighted by measurement
+      std::vector<int32_t> cnt((size_t)gpus);
+      if (nbx_group_shares(grp, NULL, cnt.data(), NULL)) die_nbx("nbx_group_shares");
+      if (root) std::printf("cpu/gpu ratio = %f\n", (double)cnt[0] / (double)n);
+      std::fflush(stdout);
+      int32_t changed = 0;
+      if (done < nsteps && nbx_group_retune(grp, NULL, &changed)) die_nbx("nbx_group_retune");
+      retunes += changed;
+    }
     if (root)
       std::cout << " " << std::left << std::setw(8) << done << std::left << std::setprecision(5) << std::setw(8)
               << done * get_tstep() << std::left << std::setprecision(5) << std::setw(12) << _kenergy << std::left
@@ -379,9 +446,15 @@ void GSimulation::start() {
 
   nbx_stats_t st;
   int32_t ranks = 1, rccl = 0;
+  std::string shares_txt;  // weighted groups: "b0 b1 ..." bodies per device at the end of the run
   // leave particles->* as the reference does after its last step (acc zeroed by the update loop)
   if (grp) {
     if (nbx_group_info(grp, &ranks, &rccl, 0, &st)) die_nbx("nbx_group_info");
+    if (weighted) {
+      std::vector<int32_t> cnt((size_t)ranks);
+      if (nbx_group_shares(grp, NULL, cnt.data(), NULL)) die_nbx("nbx_group_shares");
+      for (int r = 0; r < ranks; ++r) shares_txt += (r ? " " : "") + std::to_string(cnt[r]);
+    }
     if (nbx_group_download(grp, particles->pos_x, particles->pos_y, particles->pos_z, particles->vel_x, particles->vel_y,
                            particles->vel_z))
       die_nbx("nbx_group_download");
@@ -413,11 +486,16 @@ void GSimulation::start() {
   std::cout << "# Device             : " << st.device_name << " (" << st.cu_count << " CUs), fp" << st.precision
             << ", kernel " << kernel_name(st.kernel_variant)
             << ", " << (st.summation_order == NBX_ORDER_REFERENCE ? "reference-order" : "tree") << " sums"
-            << (st.inner_loop == NBX_LOOP_ASM ? " (hand-scheduled loop)" : st.inner_loop == NBX_LOOP_ASM_TS ? " (hand-scheduled loop, time-sliced wave priority)" : "") << ", bodies/lane " << st.bodies_per_lane << ", j-split " << st.j_split << ", grid " << st.force_grid_x << "x"
+            << (st.inner_loop == NBX_LOOP_ASM ? (st.bodies_per_lane == 1 && st.kernel_variant == NBX_KERNEL_SGPR ? " (hand-scheduled loop, two j records per packed operation)" : " (hand-scheduled loop)")
+                : st.inner_loop == NBX_LOOP_ASM_TS ? " (hand-scheduled loop, time-sliced wave priority)" : st.inner_loop == NBX_LOOP_ASM_PF ? " (hand-scheduled loop, L2 prefetch)" : "") << ", bodies/lane " << st.bodies_per_lane << ", j-split " << st.j_split << ", grid " << st.force_grid_x << "x"
             << st.force_grid_y << std::endl;
-  if (ranks > 1 || _multiprocess)
+  if (weighted)
+    std::cout << "# GPUs / shares      : " << ranks << " devices own " << shares_txt << " bodies (" << (tune ? "tuned: " + std::to_string(retunes) + " re-weighting(s) from measured force-kernel times" : "fixed weights")
+              << "), one in-place broadcast per owner and step over " << (rccl ? "RCCL" : "device-to-device copies") << std::endl;
+  else if (ranks > 1 || _multiprocess)
     std::cout << "# GPUs / ranks       : " << ranks << " x " << st.i_count << " bodies" << (_multiprocess ? " (one process per rank)" : "")
               << ", position all-gather per step over " << (rccl ? "RCCL" : "device-to-device copies") << std::endl;
+  if (!split_note.empty()) std::cout << "# Device word        : " << split_note << std::endl;
   // NBODY_JSON=<file>: the same facts as one machine-readable line (does not touch stdout)
   if (const char* jp = std::getenv("NBODY_JSON")) {
     if (FILE* jf = std::fopen(jp, "w")) {
@@ -429,11 +507,12 @@ void GSimulation::start() {
                    "{\"n\": %d, \"steps\": %d, \"precision\": %d, \"ranks\": %d, \"exchange\": \"%s\", \"total_time_s\": %.9g, "
                    "\"pair_per_s_total\": %.9g, \"gflops_avg_reference_convention\": %s, \"kenergy_last_printed\": %.17g, "
                    "\"kernel\": \"%s\", \"bodies_per_lane\": %d, \"j_split\": %d, \"grid\": [%d, %d], \"device\": \"%s\", "
-                   "\"one_process_per_rank\": %s, \"uses_rccl\": %s, \"windows\": [",
+                   "\"one_process_per_rank\": %s, \"uses_rccl\": %s, \"inner_loop\": %d, \"shares\": \"%s\", \"tuned\": %s, \"retunes\": %d, "
+                   "\"device_word_note\": \"%s\", \"windows\": [",
                    n, nsteps, st.precision, (int)ranks, ranks > 1 ? (rccl ? "rccl" : "copy") : "none", _totTime, pps, avtxt,
                    (double)_kenergy, kernel_name(st.kernel_variant),
                    st.bodies_per_lane, st.j_split, st.force_grid_x, st.force_grid_y, st.device_name, _multiprocess ? "true" : "false",
-                   rccl ? "true" : "false");
+                   rccl ? "true" : "false", (int)st.inner_loop, shares_txt.c_str(), (weighted && tune) ? "true" : "false", retunes, split_note.c_str());
       // every printed row: the step, the energy as computed (fp64 sum of the ranks' partials, before the narrowing to
       // real_type that the table shows) and the window's wall time
       for (size_t k = 0; k < windows.size(); ++k)

@@ -5,12 +5,16 @@
 // token (ncclUniqueId -> nbx_comm_unique_id / nbx_group_create_rank, include/nbx.h).  One TCP round does it:
 //   every rank r > 0 connects to rank 0 (retrying while rank 0 is still starting), sends a fixed-size hello
 //   {magic, rank, world, job signature}, and receives {status, token};
-//   rank 0 accepts connections until world-1 well-formed hellos are in (anything else on the port is dropped), checks
-//   them all (same world, distinct ranks in range, same job signature: n, steps, precision) and only THEN answers --
-//   every rank gets the same verdict, so a mis-launched or missing rank refuses the whole job at once instead of
-//   leaving the ranks that were already accepted inside ncclCommInitRank.
-// No data path runs over these sockets.  Environment (GSimulation::init_mpi): NBODY_WORLD / NBODY_RANK or torchrun's
-// WORLD_SIZE / RANK, NBODY_MASTER_ADDR / NBODY_MASTER_PORT or MASTER_ADDR / MASTER_PORT (default 127.0.0.1:29417).
+//   rank 0 accepts connections until every other rank of the job has said a well-formed hello (anything else on the port is
+//   dropped; a hello must arrive within a second of its connection), checks them all (same world, distinct ranks in range, same
+//   job signature: n, steps, precision) and only THEN answers -- every rank gets the same verdict, so a mis-launched or missing
+//   rank refuses the whole job at once instead of leaving the ranks that were already accepted inside ncclCommInitRank.  A wrong or
+//   duplicate hello does NOT take a seat: once the job is refused rank 0 keeps listening for a short grace period, so that the
+//   ranks still on their way are told "refused" too instead of finding the port closed and retrying for their whole timeout.
+// No data path runs over these sockets.  Environment (GSimulation::read_world_env): NBODY_WORLD / NBODY_RANK / NBODY_LOCAL_RANK,
+// NBODY_MASTER_ADDR / NBODY_MASTER_PORT (default 127.0.0.1:29417); torchrun's WORLD_SIZE / RANK / LOCAL_RANK / MASTER_ADDR /
+// MASTER_PORT are honoured only with NBODY_USE_TORCHRUN_ENV=1 (they are generic: a lone nbody.x that merely inherits them stays a
+// one-process run).
 #ifndef NBX_HOST_RENDEZVOUS_HPP
 #define NBX_HOST_RENDEZVOUS_HPP
 
@@ -98,27 +102,36 @@ inline bool exchange(int rank, int world, const std::string& addr, int port, con
     seen[0] = 1;
     std::vector<int> fds;  // every connection that said a well-formed hello, good or bad: all get the verdict
     bool ok = true;
-    int have = 1;
+    int have = 1;          // distinct ranks of THIS job heard so far (a wrong or duplicate hello takes no seat)
+    clock::time_point limit = deadline;  // shortened to a grace period once the job is refused
+    const std::chrono::seconds grace(3);
     while (have < world) {
-      const long left = (long)std::chrono::duration_cast<std::chrono::seconds>(deadline - clock::now()).count();
-      if (left <= 0) { *err = "rank 0 timed out waiting for " + std::to_string(world - have) + " rank(s)"; ok = false; break; }
-      timeval tv; tv.tv_sec = left; tv.tv_usec = 0;
+      const long left_ms = (long)std::chrono::duration_cast<std::chrono::milliseconds>(limit - clock::now()).count();
+      if (left_ms <= 0) {
+        if (ok) { *err = "rank 0 timed out waiting for " + std::to_string(world - have) + " rank(s)"; ok = false; }
+        break;  // refused already: the grace period for ranks still on their way is over
+      }
+      timeval tv; tv.tv_sec = left_ms / 1000; tv.tv_usec = (left_ms % 1000) * 1000;
       ::setsockopt(ls, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);  // bounds accept()
       const int fd = ::accept(ls, NULL, NULL);
       if (fd < 0) {
         if (errno == EINTR) continue;
-        *err = "rank 0 timed out waiting for " + std::to_string(world - have) + " rank(s)"; ok = false; break;
+        if (ok) { *err = "rank 0 timed out waiting for " + std::to_string(world - have) + " rank(s)"; ok = false; }
+        break;
       }
-      set_timeouts(fd, (int)(left < 10 ? left : 10));
+      set_timeouts(fd, 1);  // a rank sends its hello at once: a client that connects and says nothing costs one second, not ten
       Hello h;
       if (!recv_all(fd, &h, sizeof h) || h.magic != kMagic) { ::close(fd); continue; }  // not one of ours: ignore it
+      set_timeouts(fd, 10);
       fds.push_back(fd);
       if (h.world != world || h.rank <= 0 || h.rank >= world || seen[(size_t)h.rank] || std::memcmp(h.sig, sig, sizeof h.sig) != 0) {
-        if (ok)
+        if (ok) {
           *err = "rank " + std::to_string(h.rank) + " of " + std::to_string(h.world) + " does not belong to this job (n/steps/precision " +
                  std::to_string(h.sig[0]) + "/" + std::to_string(h.sig[1]) + "/" + std::to_string(h.sig[2]) + ", or a duplicate rank)";
-        ok = false;
-        have += 1;  // it took a seat: the job is refused as a whole once everybody has been heard (or the deadline passes)
+          ok = false;
+          // the job is refused as a whole; the ranks still on their way get the same answer if they arrive within the grace period
+          if (clock::now() + grace < limit) limit = clock::now() + grace;
+        }
         continue;
       }
       seen[(size_t)h.rank] = 1;

@@ -25,6 +25,7 @@ SYMBOLS = (
     "nbx_accel", "nbx_sync", "nbx_download", "nbx_ic_pos", "nbx_ic_vel", "nbx_ic_mass", "nbx_profile",
     "nbx_stats", "nbx_group_create", "nbx_group_destroy", "nbx_group_upload", "nbx_group_step", "nbx_group_download",
     "nbx_group_info", "nbx_partition", "nbx_comm_unique_id", "nbx_group_create_rank", "nbx_collective_timeout",
+    "nbx_partition_weighted", "nbx_group_create_weighted", "nbx_group_shares", "nbx_tune_weights", "nbx_group_retune",
 )
 
 
@@ -115,6 +116,12 @@ def load():
     L.nbx_comm_unique_id.argtypes = [vp]
     L.nbx_group_create_rank.argtypes = [ctypes.POINTER(vp), i32, i32, i32, i32, vp, i32, ctypes.POINTER(Opts)]
     L.nbx_collective_timeout.argtypes = [dbl]
+    pd = ctypes.POINTER(dbl)
+    L.nbx_partition_weighted.argtypes = [i32, i32, pd, i32] + [ctypes.POINTER(i32)] * 4
+    L.nbx_group_create_weighted.argtypes = [ctypes.POINTER(vp), i32, i32, i32, ctypes.POINTER(i32), pd, ctypes.POINTER(Opts)]
+    L.nbx_group_shares.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), pd]
+    L.nbx_tune_weights.argtypes = [i32, ctypes.POINTER(i32), pd, pd]
+    L.nbx_group_retune.argtypes = [vp, pd, ctypes.POINTER(i32)]
     _lib = L
     return L
 
@@ -250,10 +257,11 @@ class Context:
 class Group:
     """One nbx_group: n_ranks contexts driven by this process (multi-GPU; logical ranks when devices repeat)."""
 
-    def __init__(self, n, precision=32, n_ranks=1, devices=None, rank=None, unique_id=None, device=-1, **opts):
+    def __init__(self, n, precision=32, n_ranks=1, devices=None, rank=None, unique_id=None, device=-1, weights=None, weighted=False, **opts):
         """Single process: n_ranks contexts on `devices`.  One process per GPU: pass rank= and unique_id= (the 128 bytes
         of unique_id() made on rank 0 and shipped to every rank); n_ranks is then the world size and every call on the
-        group is collective (nbx_group_create_rank)."""
+        group is collective (nbx_group_create_rank).  weights= (or weighted=True for equal weights): unequal shares in whole
+        256-record tiles (nbx_group_create_weighted), which retune() can move."""
         self._L = load()
         self._h = ctypes.c_void_p()
         self.n, self.precision, self.dtype = int(n), int(precision), _dtype(precision)
@@ -267,6 +275,11 @@ class Group:
                    "nbx_group_create_rank")
             return
         dev = None if devices is None else (ctypes.c_int32 * len(devices))(*devices)
+        if weights is not None or weighted:
+            w = None if weights is None else (ctypes.c_double * len(weights))(*weights)
+            _check(self._L.nbx_group_create_weighted(ctypes.byref(self._h), self.n, self.precision, n_ranks, dev, w, ctypes.byref(o)),
+                   "nbx_group_create_weighted")
+            return
         _check(self._L.nbx_group_create(ctypes.byref(self._h), self.n, self.precision, n_ranks, dev, ctypes.byref(o)),
                "nbx_group_create")
 
@@ -294,6 +307,20 @@ class Group:
         out = {f: np.zeros(self.n, dtype=self.dtype) for f in FIELDS[:6]}
         _check(self._L.nbx_group_download(self._h, *[_ptr(out[f]) for f in FIELDS[:6]]), "nbx_group_download")
         return out
+
+    def shares(self, timings=True):
+        """nbx_group_shares: (i_begin list, i_count list, mean force-kernel ms per rank since the last retune)."""
+        P = self.info(0)[0]
+        b, c, ms = (ctypes.c_int32 * P)(), (ctypes.c_int32 * P)(), (ctypes.c_double * P)()
+        _check(self._L.nbx_group_shares(self._h, b, c, ms if timings else None), "nbx_group_shares")
+        return list(b), list(c), list(ms)
+
+    def retune(self, force_ms=None):
+        """nbx_group_retune: new shares from the measured (or the given) per-rank force-kernel times; True if they moved."""
+        ch = ctypes.c_int32(0)
+        ms = None if force_ms is None else (ctypes.c_double * len(force_ms))(*force_ms)
+        _check(self._L.nbx_group_retune(self._h, ms, ctypes.byref(ch)), "nbx_group_retune")
+        return bool(ch.value)
 
     def info(self, rank=0):
         P, rccl, st = ctypes.c_int32(), ctypes.c_int32(), Stats()
@@ -324,6 +351,22 @@ def partition(n, n_ranks, rank):
     out = [ctypes.c_int32() for _ in range(5)]
     _check(load().nbx_partition(n, n_ranks, rank, *[ctypes.byref(o) for o in out]), "nbx_partition")
     return tuple(o.value for o in out)
+
+
+def partition_weighted(n, n_ranks, weights, rank):
+    """nbx_partition_weighted: (ranks_used, i_begin, i_count, n_alloc); weights None = equal."""
+    out = [ctypes.c_int32() for _ in range(4)]
+    w = None if weights is None else (ctypes.c_double * len(weights))(*weights)
+    _check(load().nbx_partition_weighted(n, n_ranks, w, rank, *[ctypes.byref(o) for o in out]), "nbx_partition_weighted")
+    return tuple(o.value for o in out)
+
+
+def tune_weights(i_count, force_ms):
+    """nbx_tune_weights: the tuner's arithmetic (each rank's measured bodies per millisecond, normalised)."""
+    P = len(i_count)
+    out = (ctypes.c_double * P)()
+    _check(load().nbx_tune_weights(P, (ctypes.c_int32 * P)(*i_count), (ctypes.c_double * P)(*force_ms), out), "nbx_tune_weights")
+    return list(out)
 
 
 def read_snapshot(path):

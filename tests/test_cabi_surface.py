@@ -179,6 +179,15 @@ def test_every_entry_point_rejects_null_and_nonsense_without_aborting(nbx):
                                   lambda: L.nbx_group_create_rank(ctypes.byref(h), 10, 32, 1, 0, null, -1, None),
                                   lambda: L.nbx_group_create_rank(ctypes.byref(h), 300, 32, 3, 0, buf, -1, None)],  # rank 2 would be empty
         "nbx_collective_timeout": [lambda: L.nbx_collective_timeout(float("nan"))],
+        "nbx_partition_weighted": [lambda: L.nbx_partition_weighted(0, 2, None, 0, *([None] * 4)), lambda: L.nbx_partition_weighted(10, 2, None, 2, *([None] * 4)),
+                                   lambda: L.nbx_partition_weighted(1000, 2, (ctypes.c_double * 2)(1.0, -1.0), 0, *([None] * 4))],
+        "nbx_group_create_weighted": [lambda: L.nbx_group_create_weighted(None, 10, 32, 2, None, None, None),
+                                      lambda: L.nbx_group_create_weighted(ctypes.byref(h), 10, 32, 0, None, None, None),
+                                      lambda: L.nbx_group_create_weighted(ctypes.byref(h), 0, 32, 2, None, None, None)],
+        "nbx_group_shares": [lambda: L.nbx_group_shares(null, None, None, None)],
+        "nbx_tune_weights": [lambda: L.nbx_tune_weights(0, None, None, None), lambda: L.nbx_tune_weights(2, None, None, None),
+                             lambda: L.nbx_tune_weights(2, (i32 * 2)(5, 5), (ctypes.c_double * 2)(1.0, 0.0), (ctypes.c_double * 2)())],
+        "nbx_group_retune": [lambda: L.nbx_group_retune(null, None, None)],
     }
     # the remaining symbols cannot fail: they are exercised for "does not crash on NULL"
     L.nbx_destroy(null)

@@ -82,6 +82,39 @@ def test_one_verdict_for_the_whole_job(driver):
     assert all(rc == 1 and "refused by rank 0" in out for rc, out in res[1:]), res
 
 
+def test_a_wrong_hello_takes_no_seat_and_late_ranks_are_still_told(driver):
+    """a duplicate (or foreign) hello used to count as a seat, so with world = 3 a duplicate rank 1 + the real rank 1 ended
+    the accept loop before rank 2 had connected: rank 2 then found the port closed and retried for its whole timeout.  Now the wrong
+    hello refuses the job but takes no seat, and rank 0 keeps listening for a short grace period: rank 2, arriving a second later,
+    is refused at once -- long before its own 30 s timeout."""
+    port = _free_port()
+    p0 = subprocess.Popen([driver, "0", "3", str(port), "1000", "30"], stdout=subprocess.PIPE, text=True)
+    time.sleep(0.3)
+    p1 = subprocess.Popen([driver, "1", "3", str(port), "1000", "30"], stdout=subprocess.PIPE, text=True)
+    pd = subprocess.Popen([driver, "1", "3", str(port), "1000", "30"], stdout=subprocess.PIPE, text=True)   # the duplicate
+    time.sleep(1.0)
+    t0 = time.time()
+    p2 = subprocess.Popen([driver, "2", "3", str(port), "1000", "30"], stdout=subprocess.PIPE, text=True)   # still on its way
+    res = [(p.wait(timeout=60), p.stdout.read().strip()) for p in (p0, p1, pd, p2)]
+    assert time.time() - t0 < 8, res
+    assert res[0][0] == 1 and "duplicate rank" in res[0][1]
+    assert all(rc == 1 and "refused by rank 0" in out for rc, out in res[1:]), res
+
+
+def test_a_silent_client_costs_one_second_not_ten(driver):
+    port = _free_port()
+    p0 = subprocess.Popen([driver, "0", "2", str(port), "1000", "30"], stdout=subprocess.PIPE, text=True)
+    time.sleep(0.5)
+    silent = [socket.create_connection(("127.0.0.1", port), timeout=5) for _ in range(3)]   # connect and say nothing
+    t0 = time.time()
+    p1 = subprocess.Popen([driver, "1", "2", str(port), "1000", "30"], stdout=subprocess.PIPE, text=True)
+    res = [(p.wait(timeout=60), p.stdout.read().strip()) for p in (p0, p1)]
+    for c in silent:
+        c.close()
+    assert all(rc == 0 and out.startswith("ok 030a11") for rc, out in res), res
+    assert time.time() - t0 < 8     # three stalled connections in front of the real rank: ~3 s, not ~30
+
+
 def test_a_stray_connection_on_the_port_does_not_end_the_job(driver):
     """A client that is not a rank (no magic word, or a short write) is dropped; the rendezvous completes."""
     port = _free_port()
