@@ -987,11 +987,20 @@ def test_group_rccl_binding_with_one_rank(nbx):
             assert P == 1 and rccl
             g.upload(nbx.initial_conditions(3000))
             ke = g.step(20)
+        # the weighted form exchanges with one in-place ncclBroadcast per owner (blocks of unequal size): the same one-rank smoke test
+        with nbx.Group(3000, 32, n_ranks=1, devices=[0], weighted=True) as g:
+            P, rccl, _ = g.info(0)
+            assert P == 1 and rccl and g.shares(timings=False)[1] == [3000]
+            g.upload(nbx.initial_conditions(3000))
+            kew = g.step(20)
+            assert not g.retune()                    # one rank: nothing to move
+            kew2 = g.step(5)
     finally:
         del os.environ["NBX_EXCHANGE"]
     with nbx.Context(3000, use_graph=2) as c:
         c.upload(nbx.initial_conditions(3000))
-        assert c.step(20) == ke
+        assert c.step(20) == ke == kew
+        assert c.step(5) == kew2
 
 
 # ---- NBX_KERNEL_EXACT: the reference's arithmetic bit for bit ---------------------------------------------------------
