@@ -298,8 +298,10 @@ void auto_shape(nbx_ctx* c, const nbx_opts& o) {
   // Only where tree order is what AUTO takes (n <= 131072).  Above that it runs on request alone -- asked for because it is closer to the
   // true sum than the reference's single chain -- and the number of chains is what buys that: n = 262144 keeps its 8 x 4, 1M its 2 x 4.
   const bool balanced = o.j_split <= 0 && c->precision == 32 && variant == NBX_KERNEL_SGPRW && c->i_count > kRound1SplitMaxOwn && c->n <= kTreeOrderMaxN;
-  const int gran = variant == NBX_KERNEL_LDS ? kTile : (variant == NBX_KERNEL_SGPR ? 64 : (balanced ? 256 : 32));
-  static_assert(64 % kSgprAsmTrip<2> == 0 && 64 % kSgprAsmTrip<4> == 0 && 64 % kSgprAsmTrip<1> == 0 && kTile % 64 == 0, "j ranges are whole trips of the asm loop");
+  constexpr int kSgprGran = kSgprAsmTrip<1> > 64 ? kSgprAsmTrip<1> : 64;  // whole trips of every hand-scheduled loop of the plain SGPR kernel
+  const int gran = variant == NBX_KERNEL_LDS ? kTile : (variant == NBX_KERNEL_SGPR ? kSgprGran : (balanced ? 256 : 32));
+  static_assert(kSgprGran % kSgprAsmTrip<2> == 0 && kSgprGran % kSgprAsmTrip<4> == 0 && kSgprGran % kSgprAsmTrip<1> == 0 && kTile % kSgprGran == 0,
+                "j ranges are whole trips of the asm loop");
   const int max_split = std::max(1, c->n_alloc / gran);
   int S = o.j_split;
   if (S <= 0) {

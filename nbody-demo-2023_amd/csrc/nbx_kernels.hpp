@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kBlock, MINW) void force_kernel(const ForceArgs<T> 
     // wave walks a quarter of it; n_alloc is a multiple of 256)
     if constexpr (B == 1) {
       // one body per lane: two consecutive j records per packed operation, out of the pair-interleaved copy (same offsets)
-      if (j0 < j1) sgpr_loop_asm_jpair(a.posm_pairs + j0, a.posm_pairs + j1, f32x2{ib.xi[0], ib.yi[0]}, f32x2{ib.zi[0], ib.zi[0]}, (unsigned)(t & 15) * 64u, ib.ax[0], ib.ay[0], ib.az[0]);
+      if (j0 < j1) sgpr_loop_asm_jpair(a.posm_pairs + j0, a.posm_pairs + j1, f32x2{ib.xi[0], ib.yi[0]}, f32x2{ib.zi[0], ib.zi[0]}, ((unsigned)t & (kSgprJpairPrefetchLines - 1u)) * 64u + kSgprJpairPrefetchBytes, ib.ax[0], ib.ay[0], ib.az[0]);
     } else {
       if (j0 < j1) ib.apply_range_asm(a.posm + j0, a.posm + j1);
     }

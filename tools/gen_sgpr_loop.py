@@ -48,8 +48,11 @@ TBASE = 40            # first temporary VGPR (even)
 RING_A, RING_B = 36, 68
 SP, SE, SEPS = 30, 28, 34
 NEG = "neg_lo:[0,1] neg_hi:[0,1]"
-SGPR_PREFETCH = int(os.environ.get("NBX_SGPR_PREFETCH", "2"))  # B = 2 / 4 loops, _pf variants: trips ahead of the L2 prefetch
-JPAIR_GROUPS = int(os.environ.get("NBX_JPAIR_GROUPS", "8"))  # ring groups (8 records each) per trip of the jpair loop
+SGPR_PREFETCH = int(os.environ.get("NBX_SGPR_PREFETCH", "1"))  # B = 2 / 4 loops, _pf variants: trips ahead of the L2 prefetch
+# ring groups (8 records each) per trip of the jpair loop.  It only ever runs with one wave per SIMD at most, where the taken branch, the
+# pointer update and the prefetch are paid at full price: 64 / 128 / 256 records per trip measured 46.97 / 48.25 / 48.93 % at 65536 of 1M bodies
+# (profiles/r04_jpair_trip_ab.txt); 256 records = the j tile every array is padded to, 14 KB of loop.
+JPAIR_GROUPS = int(os.environ.get("NBX_JPAIR_GROUPS", "32"))
 
 
 def tmp(slot, k):
@@ -136,9 +139,7 @@ def loop_text(B, groups_per_trip, ts=False, pf=False):
     if pf:
         # L2 prefetch (see the jpair docstring paragraph): one vector load per trip, lane l touching byte 64 (l mod 16) of the trip
         # SGPR_PREFETCH trips ahead; never waited on inside the loop, destination never read
-        off = trip + SGPR_PREFETCH * trip
-        assert off <= 4095 and (SGPR_PREFETCH + 1) * (trip // 16) <= 512
-        body += ["global_load_dword v%d, %%%d, s[%d:%d] offset:%d" % (TBASE + 24, (8 if B == 2 else 14) + (2 if ts else 0), SP, SP + 1, off)]
+        body += ["global_load_dword v%d, %%%d, s[%d:%d]" % (TBASE + 24, (8 if B == 2 else 14) + (2 if ts else 0), SP, SP + 1)]
     if ts:
         body += ["s_memrealtime s[%d:%d]" % (STIME, STIME + 1)]
     body += group_ops(B, RING_A)
@@ -241,7 +242,14 @@ def jpair_group_ops(ring, odd_tail):
     return out
 
 
-JPAIR_PREFETCH = int(os.environ.get("NBX_JPAIR_PREFETCH", "2"))  # trips ahead of the L2 prefetch (0 = none)
+# Trips of the _pf variants relative to the plain loops.  They only run with ONE wave per SIMD, where the taken branch and the pointer update
+# are paid at full price: 64 / 128 / 256 records per trip measured 54.3 / 55.0 / 55.2 % for a rank of eight at n = 1M (+1.7 %), +0.8 and +1.3 % at
+# 131072 of 262144 / 524288 (profiles/r04_pf_trip_ab.txt; with two or four waves per SIMD longer trips LOSE 1-2 %, round 2 -- those shapes keep
+# the plain and the time-sliced loops).  Four bodies per lane with the prefetch is never what AUTO takes (two per lane fill the same CUs
+# with twice the workgroups): its instance keeps the short trip rather than another 11 000 lines of generated text.
+PF_TRIP_FACTOR = int(os.environ.get("NBX_PF_TRIP_FACTOR", "4"))
+PF_TRIP_FACTOR_B4 = int(os.environ.get("NBX_PF_TRIP_FACTOR_B4", "1"))
+JPAIR_PREFETCH = int(os.environ.get("NBX_JPAIR_PREFETCH", "1"))  # trips ahead of the L2 prefetch (0 = none); 2 KB ... 8 KB ahead measured alike
 VPF = TBASE + 24                                                 # destination of the prefetch load (never read)
 
 
@@ -261,9 +269,10 @@ def jpair_loop_text(groups_per_trip):
         # asks for the same line at about the same time, so what it waits for is the first requester's Infinity-Cache round trip
         # (~545 cycles).  One vector load per trip, lane l touching byte 64 (l mod 16) of the trip JPAIR_PREFETCH trips ahead,
         # pulls those 16 lines into the XCD's L2 (vmcnt is never waited on inside the loop; the destination is never read).
-        off = trip + JPAIR_PREFETCH * trip
-        assert off <= 4095 and (JPAIR_PREFETCH + 1) * (trip // 16) <= 512, "13-bit offset; reads stay inside the spare records"
-        body += ["global_load_dword v%d, %%7, s[%d:%d] offset:%d" % (VPF, SP, SP + 1, off)]
+        # (the distance travels in the VGPR operand -- pf_off = 64 (l mod 16) + kSgprJpairPrefetchBytes -- so that it is not bound by
+        # the 13-bit immediate)
+        assert (JPAIR_PREFETCH + 1) * (trip // 16) <= 512, "reads stay inside the spare records"
+        body += ["global_load_dword v%d, %%7, s[%d:%d]" % (VPF, SP, SP + 1)]
     body += jpair_group_ops(RING_A, odd_tail=False)
     body += [WAIT, "s_add_u32 s%d, s%d, s%d" % (SP, SP, SEPS + 1), "s_addc_u32 s%d, s%d, 0" % (SP + 1, SP + 1),
              "s_cmp_lg_u64 s[%d:%d], s[%d:%d]" % (SP, SP + 1, SE, SE + 1)]
@@ -294,8 +303,11 @@ def emit_jpair(groups_per_trip):
     txt.append("// `first` / `last` delimit the j range in the PAIR-INTERLEAVED copy of the record array ({x0 x1 y0 y1 | z0 z1 w0 w1} per two records,")
     txt.append("// pair_transpose_kernel): same byte offsets as in the record array, a positive multiple of kSgprAsmTrip<1> records.  xy = {xi, yi}, zz = {zi, -}.")
     txt.append("template <> constexpr int kSgprAsmTrip<1> = %d;" % (trip // 16))
-    txt.append("// pf_off = 64 * (lane mod 16): byte offset of the line this lane prefetches into L2, %d trips ahead (reads up to %d records past `last`: spare)." %
-               (JPAIR_PREFETCH, (JPAIR_PREFETCH + 1) * (trip // 16) if JPAIR_PREFETCH else 8))
+    txt.append("// pf_off = 64 * (lane mod kSgprJpairPrefetchLines) + kSgprJpairPrefetchBytes: byte offset (from the biased pointer) of the line this lane prefetches into L2, %d trips ahead" % JPAIR_PREFETCH)
+    txt.append("// (reads up to %d records past `last`: spare)." % ((JPAIR_PREFETCH + 1) * (trip // 16) if JPAIR_PREFETCH else 8))
+    txt.append("constexpr unsigned kSgprJpairPrefetchBytes = %d;" % (trip + JPAIR_PREFETCH * trip))
+    assert trip // 64 in (8, 16, 32, 64)
+    txt.append("constexpr unsigned kSgprJpairPrefetchLines = %d;  // 64-byte lines per trip: lane l touches line l mod this" % (trip // 64))
     txt.append("__device__ __forceinline__ void sgpr_loop_asm_jpair(const float4* first, const float4* last, f32x2 xy, f32x2 zz, unsigned pf_off, float& ax, float& ay, float& az) {")
     txt.append("  const char* q = reinterpret_cast<const char*>(first) - %d;     // biased: all immediate offsets positive" % trip)
     txt.append("  const char* qend = reinterpret_cast<const char*>(last) - %d;  // value of the pointer after the last trip's advance" % trip)
@@ -346,7 +358,10 @@ def emit(B, groups_per_trip, ts=False, pf=False):
         txt.append("// cover a scalar load gets, and what it waits for is an Infinity-Cache round trip; with the lines already in L2 the loop is +3.5 %.")
         txt.append("// With two or more waves per SIMD the other waves are the cover and the extra instruction costs 0.4-1.4 % (profiles/r04_b2_prefetch_ab.txt).")
         txt.append("__device__ __forceinline__ void sgpr_loop_asm_b%d_pf(const float4* first, const float4* last, %s) {" % (B, sig))
-        txt.append("  const unsigned pf_off = (threadIdx.x & 15u) * 64u;  // the line this lane touches: reads up to %d records past `last` (spare)" % ((SGPR_PREFETCH + 1) * (trip // 16)))
+        assert trip // 64 in (8, 16, 32, 64) and (SGPR_PREFETCH + 1) * (trip // 16) <= 512
+        txt.append("  // the line this lane touches, %d trips ahead (distance in the register: not bound by the 13-bit immediate); reads up to %d records past `last` (spare)" %
+                   (SGPR_PREFETCH, (SGPR_PREFETCH + 1) * (trip // 16)))
+        txt.append("  const unsigned pf_off = (threadIdx.x & %du) * 64u + %du;" % (trip // 64 - 1, trip + SGPR_PREFETCH * trip))
     else:
         txt.append("template <> constexpr int kSgprAsmTrip<%d> = %d;" % (B, trip // 16))
         txt.append("__device__ __forceinline__ void sgpr_loop_asm_b%d(const float4* first, const float4* last, %s) {" % (B, sig))
@@ -367,7 +382,7 @@ def main():
     parts = ["// nbx_sgpr_loop.inc -- GENERATED by tools/gen_sgpr_loop.py (see its docstring for the why); do not edit.",
              "// Included by nbx_kernels.hpp inside namespace nbx.  tests/test_isa_audit.py checks it is in sync with the generator.",
              "template <int B> constexpr int kSgprAsmTrip = 0;",
-             emit(2, 8), emit(4, 4), emit(2, 8, ts=True), emit(4, 4, ts=True), emit(2, 8, pf=True), emit(4, 4, pf=True), emit_jpair(JPAIR_GROUPS), ""]
+             emit(2, 8), emit(4, 4), emit(2, 8, ts=True), emit(4, 4, ts=True), emit(2, 8 * PF_TRIP_FACTOR, pf=True), emit(4, 4 * PF_TRIP_FACTOR_B4, pf=True), emit_jpair(JPAIR_GROUPS), ""]
     open(out, "w").write("\n".join(parts))
 
 
