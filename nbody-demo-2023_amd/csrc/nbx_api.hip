@@ -162,17 +162,17 @@ ForceLauncher<T> pick_force(const nbx_ctx* c, int epi) {
 // ceil(own / (256 B)) workgroups are spread over the CUs, and a launch takes as long as the fullest CU, which holds
 // r = ceil(workgroups / CUs) of them.  Measured on MI355X at n = 1048576 with the hand-scheduled loop for B = 2 and 4
 // (profiles/r02_reference_order_thresholds.txt), ms for r = 1, 2, 3, ...: B = 1, compiled loop: 31.0, 48.6, 70.3, 91, 112 (plain VALU ops);
-// B = 2: 31.5 (30.5 with the L2 prefetch of LOOP_ASM_PF, round 4), 59.6, 88.5, 118;  B = 4: 59.3, 117.4, 175.6, 234.6 -- linear in r after
+// B = 2: 31.5 (30.0 with the L2 prefetch and the 256-record trips of LOOP_ASM_PF, round 4), 59.6, 88.5, 118;  B = 4: 59.3, 117.4, 175.6, 234.6 -- linear in r after
 // the first workgroup.  With two workgroups on the fullest CU the time-sliced loop applies (LOOP_ASM_TS): B = 2, r = 2 then costs 58.0
 // (profiles/r02_time_sliced_ab.txt: 57.98 ms for 262144 of 1M bodies), B = 4, r = 2 117.0.  Round 4: one body per lane with the
-// two-j-records-per-operation loop (sgpr_loop_asm_jpair, `jpair`): 18.7 for r = 1 (65536 of 1M bodies: 46.8 % of the roofline against 28.4 %
-// for the compiled loop and 27.8 % for B = 2 on half the CUs), 37.6 for r = 2 (profiles/r04_jpair_ab.txt) -- so it takes every slice of up to
+// two-j-records-per-operation loop (sgpr_loop_asm_jpair, `jpair`): 17.9 for r = 1 (65536 of 1M bodies: 48.8 % of the roofline against 28.4 %
+// for the compiled loop and 27.8 % for B = 2 on half the CUs), 34.3 for r = 2 (profiles/r04_jpair_ab.txt) -- so it takes every slice of up to
 // 256 x CUs = 65536 bodies, and B = 2 keeps 65537 ... 131072.  Pick the B with the smallest estimate; ties go to the larger B (fewer
 // workgroups stream the j records).  Only the ratios matter, so the table serves every n.
 int reference_order_bodies_per_lane(int own, int cus, int max_b, bool jpair) {
   struct Cost { int b; double first, next, two; };
-  static const Cost kCost[] = {{1, 31.0, 20.2, 0.0}, {2, 30.5, 29.8, 58.0}, {4, 59.8, 58.2, 117.0}};
-  static const Cost kJpair = {1, 18.7, 18.9, 0.0};  // one body per lane, two j records per packed operation
+  static const Cost kCost[] = {{1, 31.0, 20.2, 0.0}, {2, 30.0, 29.25, 58.0}, {4, 59.8, 58.2, 117.0}};
+  static const Cost kJpair = {1, 17.9, 16.4, 0.0};  // one body per lane, two j records per packed operation
   int best = 1;
   double best_t = 0.0;
   for (const auto& k0 : kCost) {

@@ -852,6 +852,10 @@ def test_cli_cpu_plus_gpu_maps_onto_unequal_shares_and_the_tuner(tmp_path):
     assert d["shares"] == "4096 12288" and d["ranks"] == 2 and not d["tuned"]
     assert any(ln.startswith("# GPUs / shares") and "4096 12288" in ln and "fixed weights" in ln for ln in lines)
     assert [r[2][:5] for r in _rows(lines)] == [r[2][:5] for r in _rows(base)]   # tree order at this n: the same to the printed digits' noise
+    rc, lines, err = _run_cli("nbody.x", 16384, 100, env={"NBODY_GPUS": "3", "NBODY_WEIGHTS": "1,2,1", "NBODY_JSON": j2})   # the same without the device word
+    assert rc == 0 and json.load(open(j2))["shares"] == "4096 8192 4096", err
+    rc, lines, err = _run_cli("nbody.x", 16384, 100, env={"NBODY_GPUS": "3", "NBODY_WEIGHTS": "1,2"})
+    assert rc == 1 and "NBODY_WEIGHTS needs 3" in err
     rc, lines, err = _run_cli("nbody_v5.x", 16384, 150, "cpu+gpu", -1, env={"NBODY_GPUS": "2", "NBODY_JSON": j2})
     assert rc == 0, err
     d = json.load(open(j2))
@@ -1396,6 +1400,33 @@ def test_weighted_shares_and_retuning_change_no_bit_in_reference_order(nbx):
         with nbx.Group(5001, 32, n_ranks=2, devices=[0, 0]) as g:
             g.upload(nbx.initial_conditions(5001))
             g.retune()
+
+
+@pytest.mark.parametrize("prec,tol", [(32, 2e-6), (64, 1e-12)])
+def test_weighted_shares_in_tree_order_and_fp64_stay_inside_the_rounding_band(nbx, prec, tol):
+    """Tree order: the summation tree of a body depends on the launch shape of whoever owns it, so shares and retunes move results
+    by rounding only -- energies of a weighted, retuned group against one context (fp32 2e-6 after 30 steps, fp64 1e-12), every body
+    stepped exactly once per step (positions close to the single context's everywhere)."""
+    n, steps = 20000, 10
+    ic = nbx.initial_conditions(n, prec)
+    with nbx.Context(n, prec) as c:
+        c.upload(ic)
+        assert c.stats()["summation_order"] == nbx.ORDER_TREE
+        ke_ref = [c.step(steps) for _ in range(3)]
+        ref = c.download()
+    with nbx.Group(n, prec, n_ranks=2, devices=[0, 0], weights=[1, 3]) as g:
+        g.upload(ic)
+        assert g.shares(timings=False)[1] == [5120, 14880]
+        ke = [g.step(steps)]
+        assert g.retune([3.0, 1.0])                                     # now rank 0 is the fast one
+        assert g.shares(timings=False)[1][0] > 5120
+        ke.append(g.step(steps))
+        g.retune()
+        ke.append(g.step(steps))
+        got = g.download()
+    assert max(abs(a / b - 1.0) for a, b in zip(ke, ke_ref)) < tol, (ke, ke_ref)
+    for f in ref:
+        assert np.allclose(got[f], ref[f], rtol=1e-4 if prec == 32 else 1e-10, atol=1e-5 if prec == 32 else 1e-12), f
 
 
 def test_auto_order_threshold(nbx):
