@@ -99,6 +99,7 @@ struct nbx_group {
   std::vector<char> mass_host;       // the masses as uploaded (n elements of the group's precision): needed to re-upload after a retune
   bool uploaded = false;
   long long retunes = 0;
+  bool broken = false;               // a retune failed half-way (contexts could not be rebuilt): only nbx_group_destroy is left
 };
 
 namespace {
@@ -414,6 +415,7 @@ int nbx_tune_weights(int32_t n_ranks, const int32_t* i_count, const double* forc
 int nbx_group_shares(nbx_group* g, int32_t* i_begin, int32_t* i_count, double* force_ms) {
   return guarded("nbx_group_shares", [&]() -> int {
   if (!g) return fail(NBX_ERR_ARG, "nbx_group_shares: group is NULL");
+  if (g->broken) return fail(NBX_ERR_STATE, "nbx_group_shares: a retune failed while rebuilding the contexts; destroy the group");
   for (int r = 0; r < g->P; ++r) {
     if (i_begin) i_begin[r] = g->begin[r];
     if (i_count) i_count[r] = g->count[r];
@@ -437,6 +439,7 @@ int nbx_group_retune(nbx_group* g, const double* force_ms, int32_t* changed) {
   if (changed) *changed = 0;
   if (!g) return fail(NBX_ERR_ARG, "nbx_group_retune: group is NULL");
   if (!g->weighted || g->my_rank >= 0) return fail(NBX_ERR_STATE, "nbx_group_retune: needs a single-process group made by nbx_group_create_weighted");
+  if (g->broken) return fail(NBX_ERR_STATE, "nbx_group_retune: an earlier retune failed while rebuilding the contexts; destroy the group");
   if (!g->uploaded) return fail(NBX_ERR_STATE, "nbx_group_retune: nbx_group_upload has not been called");
   std::vector<double> ms((size_t)g->P), w((size_t)g->P);
   if (force_ms) {
@@ -473,12 +476,14 @@ int nbx_group_retune(nbx_group* g, const double* force_ms, int32_t* changed) {
   rc = nbx_group_download(g, a[0], a[1], a[2], a[3], a[4], a[5]);
   if (rc) return rc;
   g->begin = b; g->count = c; g->weight = w;
+  g->broken = true;  // until every new context exists and holds the state
   rc = make_contexts(g, "nbx_group_retune");
   if (rc) return rc;
   for (nbx_ctx* x : g->rank) {
     rc = nbx_upload(x, a[0], a[1], a[2], a[3], a[4], a[5], g->mass_host.data());
     if (rc) return rc;
   }
+  g->broken = false;
   g->steps_unsynced = 0;
   g->step_s_est = 0.0;
   g->retunes += 1;
@@ -523,6 +528,7 @@ int nbx_group_create_rank(nbx_group** out, int32_t n, int32_t precision, int32_t
   if (!g) return fail(NBX_ERR_ALLOC, "nbx_group_create_rank: out of host memory");
   struct Owner { nbx_group* g; ~Owner() { nbx_group_destroy(g); } } owner{g};
   g->n = n; g->precision = precision; g->P = P; g->block = block; g->n_alloc = P * block; g->my_rank = rank;
+  for (int r = 0; r < P; ++r) { g->begin.push_back(r * block); g->count.push_back(std::min(n, (r + 1) * block) - r * block); }
   g->dev.push_back(dev);
   o.device = dev;
   o.i_begin = rank * block;
@@ -596,6 +602,7 @@ int nbx_group_step(nbx_group* g, double dt, int32_t nsteps, double* kenergy_out)
   return guarded("nbx_group_step", [&]() -> int {
   if (!g) return fail(NBX_ERR_ARG, "nbx_group_step: group is NULL");
   if (nsteps < 0) return fail(NBX_ERR_ARG, "nbx_group_step: nsteps < 0");
+  if (g->broken) return fail(NBX_ERR_STATE, "nbx_group_step: a retune failed while rebuilding the contexts; destroy the group");
   const auto t_enter = std::chrono::steady_clock::now();
   const bool window_from_sync = g->steps_unsynced == 0;  // everything this call waits for was enqueued by this call
   g->steps_unsynced += nsteps;
@@ -664,6 +671,7 @@ int nbx_group_step(nbx_group* g, double dt, int32_t nsteps, double* kenergy_out)
 int nbx_group_download(nbx_group* g, void* px, void* py, void* pz, void* vx, void* vy, void* vz) {
   return guarded("nbx_group_download", [&]() -> int {
   if (!g) return fail(NBX_ERR_ARG, "nbx_group_download: group is NULL");
+  if (g->broken) return fail(NBX_ERR_STATE, "nbx_group_download: a retune failed while rebuilding the contexts; destroy the group");
   Watchdog::Scope bounded("nbx_group_download (stream synchronisation + all-gather of the velocities)", queued_allowance(g));
   struct Synced { nbx_group* g; ~Synced() { g->steps_unsynced = 0; } } synced{g};
   for (nbx_ctx* c : g->rank) {

@@ -1719,6 +1719,10 @@ def test_rank_group_world_of_one_matches_a_plain_context(nbx):
         ke = g.step(steps)
         got = g.download()
         P, rccl, st = g.info(0)
+        b, cnt, ms = g.shares()                       # a rank group knows the whole partition and its own timing (none: not profiled)
+        assert b == [0] and cnt == [n] and ms == [0.0]
+        with pytest.raises(nbx.NbxError):             # unequal shares exist for the single-process form only
+            g.retune()
     assert P == 1 and rccl and st["i_count"] == n
     assert ke == ke_ref
     for f in ref:
