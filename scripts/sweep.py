@@ -107,8 +107,22 @@ def time_group(n, k, precision, ic, target_s=0.5, order=0):
     return {"ranks_used": P, "steps": steps, "s_per_step": wall, "uses_rccl": rccl, "kenergy": ke, "shape": _shape(st)}
 
 
+def cpu_baseline(precision):
+    """north_star: "alongside the reference ver7 OpenMP CPU path timed on the same box's host cores (core count stated) in the same
+    run" -- bench.py's cpu_baseline leg (the reference's own ver7 binary from oracle/_ref when it is there, else the oracle's C
+    restatement), run BEFORE this process touches the GPU."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench.cpu_baseline("auto", 262144, precision)
+
+
 def multi_gpu_grid(a, gpus):
     """n x gpus grid; every cell says whether it was measured on that many devices or is the one-GPU slice proxy."""
+    cpu = None if a.no_cpu else cpu_baseline(a.precision)
+    if cpu:
+        print("CPU baseline: %.3g pair/s on %d threads (%s)" % (cpu["value"], cpu["cores"], cpu["sample"]), flush=True)
     try:
         import torch
         ndev = torch.cuda.device_count()
@@ -143,7 +157,7 @@ def multi_gpu_grid(a, gpus):
                 "" if cell["ranks_used"] == k else "  (%d ranks: no rank may be empty)" % cell["ranks_used"]), flush=True)
         n *= 2
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
-    json.dump({"precision": a.precision, "peak_flops_per_gpu": PEAK[a.precision], "flop_per_pair": 20, "devices_on_box": ndev,
+    json.dump({"precision": a.precision, "peak_flops_per_gpu": PEAK[a.precision], "flop_per_pair": 20, "devices_on_box": ndev, "cpu_baseline": cpu,
                "what": "SURVEY.md 8(d) grid n = 2048 * 2^k x GPUs; measured = run on that many devices (nbx.Group, single process, RCCL), otherwise the one-GPU "
                        "slice proxy: rank 0's block of the library's partition against all resident records, before communication and skew",
                "cells": cells}, open(a.out, "w"), indent=1)
@@ -156,6 +170,7 @@ def main():
     ap.add_argument("--precision", type=int, default=32)
     ap.add_argument("--order", default="auto", choices=("auto", "reference", "tree"))
     ap.add_argument("--gpus", default="", help="comma-separated GPU counts, e.g. 1,2,4,8: the n x GPUs grid (measured where the box has the devices, else the slice proxy)")
+    ap.add_argument("--no-cpu", action="store_true", help="--gpus grid: skip the CPU baseline (the reference's ver7 on this box's cores, ~20 s)")
     a = ap.parse_args()
     if a.gpus:
         return multi_gpu_grid(a, [int(x) for x in a.gpus.split(",")])
