@@ -322,6 +322,8 @@ void GSimulation::start() {
     }
     if (root && !split_note.empty()) std::cerr << "nbody.x: " << split_note << std::endl;
   }
+  if (root && (tune || !weights.empty()) && (_multiprocess || gpus < 2))
+    std::cerr << "nbody.x: NBODY_WEIGHTS / NBODY_TUNE apply to the single-process form with NBODY_GPUS >= 2 only; equal blocks are used" << std::endl;
   const bool weighted = !_multiprocess && gpus >= 2 && (tune || !weights.empty());
   nbx_ctx* ctx = NULL;
   nbx_group* grp = NULL;
