@@ -248,6 +248,7 @@ def jpair_group_ops(ring, odd_tail):
 # the plain and the time-sliced loops).  Four bodies per lane with the prefetch is never what AUTO takes (two per lane fill the same CUs
 # with twice the workgroups): its instance keeps the short trip rather than another 11 000 lines of generated text.
 PF_TRIP_FACTOR = int(os.environ.get("NBX_PF_TRIP_FACTOR", "4"))
+TS_TRIP_FACTOR = int(os.environ.get("NBX_TS_TRIP_FACTOR", "1"))  # experiment knob: trips of the time-sliced variants (two waves per SIMD)
 PF_TRIP_FACTOR_B4 = int(os.environ.get("NBX_PF_TRIP_FACTOR_B4", "1"))
 JPAIR_PREFETCH = int(os.environ.get("NBX_JPAIR_PREFETCH", "1"))  # trips ahead of the L2 prefetch (0 = none); 2 KB ... 8 KB ahead measured alike
 VPF = TBASE + 24                                                 # destination of the prefetch load (never read)
@@ -382,7 +383,7 @@ def main():
     parts = ["// nbx_sgpr_loop.inc -- GENERATED by tools/gen_sgpr_loop.py (see its docstring for the why); do not edit.",
              "// Included by nbx_kernels.hpp inside namespace nbx.  tests/test_isa_audit.py checks it is in sync with the generator.",
              "template <int B> constexpr int kSgprAsmTrip = 0;",
-             emit(2, 8), emit(4, 4), emit(2, 8, ts=True), emit(4, 4, ts=True), emit(2, 8 * PF_TRIP_FACTOR, pf=True), emit(4, 4 * PF_TRIP_FACTOR_B4, pf=True), emit_jpair(JPAIR_GROUPS), ""]
+             emit(2, 8), emit(4, 4), emit(2, 8 * TS_TRIP_FACTOR, ts=True), emit(4, 4 * TS_TRIP_FACTOR, ts=True), emit(2, 8 * PF_TRIP_FACTOR, pf=True), emit(4, 4 * PF_TRIP_FACTOR_B4, pf=True), emit_jpair(JPAIR_GROUPS), ""]
     open(out, "w").write("\n".join(parts))
 
 
