@@ -100,6 +100,10 @@ struct nbx_group {
   bool uploaded = false;
   long long retunes = 0;
   bool broken = false;               // a retune failed half-way (contexts could not be rebuilt): only nbx_group_destroy is left
+  // the tuner accepts improvements only: the shares in force before the last move and the slowest rank's time under them
+  std::vector<int> prev_begin, prev_count;
+  double prev_max_ms = 0.0;          // 0 = no move to judge
+  bool tuning_frozen = false;        // a move made the step slower and was taken back: the shares stay where they are
 };
 
 namespace {
@@ -450,12 +454,6 @@ int nbx_group_retune(nbx_group* g, const double* force_ms, int32_t* changed) {
     for (int r = 0; r < g->P; ++r)
       if (!(ms[r] > 0.0)) return NBX_OK;  // a rank without a timed launch since the last retune: nothing to weigh by, shares stay
   }
-  int rc = nbx_tune_weights(g->P, g->count.data(), ms.data(), w.data());
-  if (rc) return rc;
-  std::vector<int> b, c;
-  int na = 0;
-  rc = partition_weighted(g->n, g->P, w.data(), &b, &c, &na);
-  if (rc) return rc;
   // restart the measurement window whether or not the shares move
   auto restart_timing = [&]() -> int {
     for (nbx_ctx* x : g->rank) {
@@ -465,7 +463,29 @@ int nbx_group_retune(nbx_group* g, const double* force_ms, int32_t* changed) {
     }
     return NBX_OK;
   };
-  if ((int)b.size() != g->P || na != g->n_alloc || c == g->count) return restart_timing();  // same shares (or the 256-record tiles allow no finer step)
+  // The step lasts as long as the slowest rank.  A rank's time is NOT linear in its share: a reference-order launch lasts as long as
+  // its fullest SIMD, so one body more than a whole number of waves per SIMD costs a whole extra wave there (131072 bodies of 1M: 30 ms,
+  // 131073: 58 ms).  The rate-proportional move below cannot know that, so it is judged by its result: if the window after a move was
+  // slower than the window before it, the move is taken back and the shares are left alone from then on.
+  double cur_max = 0.0;
+  for (int r = 0; r < g->P; ++r) cur_max = std::max(cur_max, ms[r]);
+  std::vector<int> b, c;
+  int na = g->n_alloc;
+  int rc = NBX_OK;
+  if (g->prev_max_ms > 0.0 && cur_max > 1.01 * g->prev_max_ms) {
+    b = g->prev_begin; c = g->prev_count;   // back to the shares that were faster
+    g->tuning_frozen = true;
+    g->prev_max_ms = 0.0;
+  } else {
+    g->prev_max_ms = 0.0;
+    if (g->tuning_frozen) return restart_timing();
+    rc = nbx_tune_weights(g->P, g->count.data(), ms.data(), w.data());
+    if (rc) return rc;
+    rc = partition_weighted(g->n, g->P, w.data(), &b, &c, &na);
+    if (rc) return rc;
+    if ((int)b.size() != g->P || na != g->n_alloc || c == g->count) return restart_timing();  // same shares (or the 256-record tiles allow no finer step)
+    g->prev_begin = g->begin; g->prev_count = g->count; g->prev_max_ms = cur_max;
+  }
   // Shares move: velocities live with their owners, so the state goes through the host once -- positions from rank 0 (every rank holds
   // them all), velocities from each owner -- and comes back to contexts with the new slices.  Values are copied, never recomputed: the
   // trajectory is the same bit for bit in reference summation order, whoever owns a body (tests compare).
@@ -475,7 +495,9 @@ int nbx_group_retune(nbx_group* g, const double* force_ms, int32_t* changed) {
   for (int k = 0; k < 6; ++k) a[k] = h.data() + (size_t)k * es * (size_t)g->n;
   rc = nbx_group_download(g, a[0], a[1], a[2], a[3], a[4], a[5]);
   if (rc) return rc;
-  g->begin = b; g->count = c; g->weight = w;
+  g->begin = b; g->count = c;
+  g->weight.assign((size_t)g->P, 0.0);
+  for (int r = 0; r < g->P; ++r) g->weight[r] = (double)c[r] / (double)g->n;
   g->broken = true;  // until every new context exists and holds the state
   rc = make_contexts(g, "nbx_group_retune");
   if (rc) return rc;

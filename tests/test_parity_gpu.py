@@ -1402,6 +1402,42 @@ def test_weighted_shares_and_retuning_change_no_bit_in_reference_order(nbx):
             g.retune()
 
 
+def test_the_tuner_takes_back_a_move_that_made_the_step_slower(nbx):
+    """A rank's time is a step function of its share in reference order (a launch lasts as long as its fullest SIMD: 131072 bodies of 1M
+    take 30 ms, 131073 take 58), which a rate-proportional move cannot know.  So nbx_group_retune judges every move by the window that
+    follows it: slower than before (the slowest rank's time rose by more than 1 %) -> the previous shares come back and stay."""
+    n = 5001
+    ic = nbx.initial_conditions(n)
+    with nbx.Context(n, 32, summation_order=nbx.ORDER_REFERENCE) as c:
+        c.upload(ic)
+        c.step(9, kenergy=False)
+        ref = c.download()
+    with nbx.Group(n, 32, n_ranks=3, devices=[0, 0, 0], weighted=True, summation_order=nbx.ORDER_REFERENCE) as g:
+        g.upload(ic)
+        first = g.shares(timings=False)[1]
+        g.step(3, kenergy=False)
+        assert g.retune([1.0, 2.0, 1.0])                         # slowest rank 2.0: shares move towards ranks 0 and 2
+        moved = g.shares(timings=False)[1]
+        assert moved != first and moved[1] < first[1]
+        g.step(3, kenergy=False)
+        assert g.retune([3.0, 0.5, 3.0])                         # the window after the move: slowest rank 3.0 > 2.0 -> taken back
+        assert g.shares(timings=False)[1] == first
+        g.step(3, kenergy=False)
+        assert not g.retune([1.0, 2.0, 1.0])                     # and the shares are left alone from then on
+        assert g.shares(timings=False)[1] == first
+        got = g.download()
+    for f in ref:
+        assert np.array_equal(got[f], ref[f]), f                 # moves and the way back copied values, bit for bit
+    with nbx.Group(n, 32, n_ranks=3, devices=[0, 0, 0], weighted=True, summation_order=nbx.ORDER_REFERENCE) as g:
+        g.upload(ic)
+        g.step(2, kenergy=False)
+        assert g.retune([1.0, 2.0, 1.0])
+        after = g.shares(timings=False)[1]
+        g.step(2, kenergy=False)
+        assert not g.retune([x * 1.3 / y for x, y in zip(after, g.shares(timings=False)[1])])   # equal times, faster than before: kept, fixed point
+        assert g.shares(timings=False)[1] == after
+
+
 @pytest.mark.parametrize("prec,tol", [(32, 2e-6), (64, 1e-12)])
 def test_weighted_shares_in_tree_order_and_fp64_stay_inside_the_rounding_band(nbx, prec, tol):
     """Tree order: the summation tree of a body depends on the launch shape of whoever owns it, so shares and retunes move results
