@@ -251,9 +251,11 @@ int nbx_partition(int32_t n, int32_t n_ranks, int32_t rank, int32_t* ranks_used,
  *                              for bit whoever owns a body).  *changed = 1 if the shares moved.  Call it between windows, e.g.
  *                              after every nbx_group_step that asked for the energy (nbody.x: every printed row, like the reference).
  *                              A rank's time is not linear in its share (a reference-order launch lasts as long as its fullest
- *                              SIMD: one body beyond a whole number of waves per SIMD costs a whole extra wave), so every move is
- *                              judged by the window after it: if the slowest rank got slower by more than 1 %, the previous shares
- *                              come back (*changed = 1) and stay -- the tuner accepts improvements only.
+ *                              SIMD: one body beyond a whole number of waves per SIMD costs a whole extra wave), so (1) a move is
+ *                              first predicted -- each rank's measured time scaled by the library's own launch-cost table for the
+ *                              old and the new share -- and not made unless the slowest rank is expected to gain at least 1 %, and
+ *                              (2) every move made is judged by the window after it: if the slowest rank got slower by more than
+ *                              1 %, the previous shares come back (*changed = 1) and stay.  The tuner accepts improvements only.
  */
 int nbx_partition_weighted(int32_t n, int32_t n_ranks, const double* weights, int32_t rank, int32_t* ranks_used, int32_t* i_begin,
                            int32_t* i_count, int32_t* n_alloc);

@@ -169,7 +169,7 @@ ForceLauncher<T> pick_force(const nbx_ctx* c, int epi) {
 // for the compiled loop and 27.8 % for B = 2 on half the CUs), 34.3 for r = 2 (profiles/r04_jpair_ab.txt) -- so it takes every slice of up to
 // 256 x CUs = 65536 bodies, and B = 2 keeps 65537 ... 131072.  Pick the B with the smallest estimate; ties go to the larger B (fewer
 // workgroups stream the j records).  Only the ratios matter, so the table serves every n.
-int reference_order_bodies_per_lane(int own, int cus, int max_b, bool jpair) {
+int reference_order_bodies_per_lane(int own, int cus, int max_b, bool jpair, double* cost_out = nullptr) {
   struct Cost { int b; double first, next, two; };
   static const Cost kCost[] = {{1, 31.0, 20.2, 0.0}, {2, 30.0, 29.25, 58.0}, {4, 59.8, 58.2, 117.0}};
   static const Cost kJpair = {1, 17.9, 16.4, 0.0};  // one body per lane, two j records per packed operation
@@ -187,6 +187,7 @@ int reference_order_bodies_per_lane(int own, int cus, int max_b, bool jpair) {
   // by 2.5 % at 262144 owned bodies and tie from 524288 up (the younger wave of a SIMD fills the older one's issue bubbles;
   // profiles/r02_loop_ab_asm_vs_cxx.txt, same process on two boxes): take them.
   if (best == 4 && max_b >= 2 && ceil_div(own, kBlock * 2) % std::max(1, cus) == 0) best = 2;
+  if (cost_out) *cost_out = best_t;
   return best;
 }
 
@@ -488,6 +489,20 @@ int drain_profile(nbx_ctx* c) {
 }
 
 }  // namespace
+// What one force launch of this context would cost, in relative units, if the context owned `own` bodies instead: the cost table of
+// reference_order_bodies_per_lane in reference order (a step function of `own`: the launch lasts as long as its fullest CU), and `own`
+// itself in tree order, where j-splits keep the time close to proportional.  The tuner of nbx_group_retune uses the RATIO of two such
+// values to predict what a move of the shares would do before it makes it.
+double nbx_detail::model_force_cost(const nbx_ctx* c, int own) {
+  if (own <= 0) return 0.0;
+  if (c->order != NBX_ORDER_REFERENCE) return (double)own;
+  const int cus = c->prop.multiProcessorCount > 0 ? c->prop.multiProcessorCount : 256;
+  const bool jpair = c->precision == 32 && c->variant == NBX_KERNEL_SGPR;
+  double t = 0.0;
+  (void)reference_order_bodies_per_lane(own, cus, c->precision == 32 ? 8 : 4, jpair, &t);
+  return t;
+}
+
 int nbx_detail::use_device(nbx_ctx* c) {
   HIP_TRY(hipSetDevice(c->device));
   return NBX_OK;

@@ -484,6 +484,16 @@ int nbx_group_retune(nbx_group* g, const double* force_ms, int32_t* changed) {
     rc = partition_weighted(g->n, g->P, w.data(), &b, &c, &na);
     if (rc) return rc;
     if ((int)b.size() != g->P || na != g->n_alloc || c == g->count) return restart_timing();  // same shares (or the 256-record tiles allow no finer step)
+    // Predict before moving: rank r's time under the new shares = its measured time x model(new share) / model(present share), with the
+    // library's own cost table as the model (a step function of the share in reference order).  A move that the model expects to make
+    // the slowest rank slower -- e.g. across a one-workgroup-per-CU boundary -- is not made.
+    double predicted = 0.0;
+    for (int r = 0; r < g->P; ++r) {
+      const nbx_ctx* x = g->rank[(size_t)r];
+      const double now = model_force_cost(x, g->count[r]), then = model_force_cost(x, c[r]);
+      predicted = std::max(predicted, now > 0.0 ? ms[r] * then / now : ms[r]);
+    }
+    if (predicted > 0.99 * cur_max) return restart_timing();
     g->prev_begin = g->begin; g->prev_count = g->count; g->prev_max_ms = cur_max;
   }
   // Shares move: velocities live with their owners, so the state goes through the host once -- positions from rank 0 (every rank holds

@@ -86,5 +86,6 @@ struct nbx_ctx {
 namespace nbx_detail {
 // shared by the context entry points (nbx_api.hip) and the groups (nbx_group.hip)
 int use_device(nbx_ctx* c);
+double model_force_cost(const nbx_ctx* c, int own);  // relative cost of one force launch if the context owned `own` bodies (the tuner's predictor)
 int enqueue_ke_reduce(nbx_ctx* c, int slot);  // ke_part[0 .. ke_parts) -> ke_dev[slot], fixed order, on the context's stream
 }  // namespace nbx_detail
