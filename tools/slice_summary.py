@@ -32,10 +32,12 @@ def counters(d, variant, pas):
 
 def main():
     d, tag, n, own = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+    before = sys.argv[5] if len(sys.argv) > 5 else "cxx"
     out = {"what": "one rank's slice: bodies [0, %d) of n = %d, reference summation order, force kernel with the row epilogue; per launch" % (own, n),
            "n": n, "bodies_owned": own, "simds_on_chip": 1024, "variants": {}}
-    for v, label in (("cxx", "before (round 3): one body per lane, compiled loop, plain VALU instructions"),
-                     ("auto", "after (round 4): what the library takes now")):
+    labels = {"cxx": "before (round 3): one body per lane, compiled loop, plain VALU instructions",
+              "asm2": "before (round 3): two bodies per lane, plain hand-scheduled loop (64-record trips, no L2 prefetch)"}
+    for v, label in ((before, labels[before]), ("auto", "after (round 4): what the library takes now")):
         sq, ms_sq, name, grid, launches = counters(d, v, "sq")
         grbm, ms_g, _, _, _ = counters(d, v, "grbm")
         fetch, ms_f, _, _, _ = counters(d, v, "fetch")
@@ -63,11 +65,11 @@ def main():
             "chip_valu_utilisation": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] * min(1.0, waves / 1024.0),
             "FETCH_SIZE_MB": fetch["FETCH_SIZE"] * 1024 / 1e6, "raw": {**sq, **grbm, **fetch},
         }
-    a, b = out["variants"]["cxx"], out["variants"]["auto"]
+    a, b = out["variants"][before], out["variants"]["auto"]
     out["speedup"] = a["avg_launch_ms_kernel_trace"] / b["avg_launch_ms_kernel_trace"]
     path = os.path.join("profiles", "%s_slice_pmc_summary.json" % tag)
     json.dump(out, open(path, "w"), indent=1)
-    for v in ("cxx", "auto"):
+    for v in (before, "auto"):
         x = out["variants"][v]
         print("%-5s %s: %d workgroups, %.3f ms, %.1f %% of the roofline; %.2f waves/SIMD; %.1f cycles per j record per wave at %.2f GHz; VALU %.2f, SALU %.3f, SMEM %.3f instructions "
               "per record; VALU busy %.3f of the wave's cycles, waiting %.3f; FETCH %.1f MB" % (
