@@ -79,8 +79,10 @@ typedef struct nbx_opts {
   int32_t i_count;         /* bodies owned; 0 = all n (single-GPU) */
   int32_t n_alloc;         /* length of the device {x,y,z,G*m} array, >= n; 0 = n rounded up to the
                               j-tile.  Ranks of one job pass the same value (= ranks * block). */
-  int32_t bodies_per_lane; /* register blocking of i-bodies: 1,2,4,8; 0 = auto */
-  int32_t j_split;         /* workgroups sharing one i-block, each summing a j-range; 0 = auto */
+  int32_t bodies_per_lane; /* register blocking of i-bodies: 1,2,4,8; 0 = auto (reference order: by a measured cost model of the launch --
+                              1 for slices of up to 256 x CUs bodies and wherever 256-body workgroups load the CUs more evenly, else 2 or 4) */
+  int32_t j_split;         /* workgroups sharing one i-block, each summing a j-range; 0 = auto.  Explicit splits of NBX_KERNEL_LDS and
+                              NBX_KERNEL_SGPR are whole 256-record tiles, of NBX_KERNEL_SGPRW multiples of 32 records */
   int32_t kernel_variant;  /* NBX_KERNEL_* */
   int32_t fused_epilogue;  /* 0 / 1 = integrate inside the force kernel where the shape allows it (j_split == 1 without
                               wave split, and NBX_KERNEL_JLANE); shapes with j-splits always run the separate integrate
