@@ -173,7 +173,10 @@ class ShardedSimulation:
     initialised (nccl == RCCL on ROCm; gloo for CPU rehearsals), or None for a single rank.
     """
 
-    def __init__(self, n, precision=32, dist=None, engine_factory=None, force_collective=False, **opts):
+    def __init__(self, n, precision=32, dist=None, engine_factory=None, force_collective=False, weights=None, **opts):
+        """weights (one positive number per rank, the same list on every rank): unequal shares in whole 256-record tiles
+        (nbx_partition_weighted: the reference's `cpu+gpu <ratio>` split with GPUs as the devices, include/nbx.h); the per-step
+        exchange is then one in-place broadcast per owner instead of the equal-block all-gather."""
         self.n = int(n)
         self.precision = precision
         # a 1-rank group skips the collectives unless force_collective (used to rehearse the RCCL path on one GPU)
@@ -181,8 +184,21 @@ class ShardedSimulation:
         self.dist = dist if use else None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.rank = self.dist.get_rank() if self.dist else 0
-        check_world(self.n, self.world)  # collective decision: raises on all ranks or on none
-        self.block, self.i_begin, self.i_count, self.n_alloc = block_partition(self.n, self.world, self.rank)
+        self.shares = None  # weighted form: [(i_begin, i_count)] of every rank
+        if weights is not None and self.world > 1:
+            if len(weights) != self.world:
+                raise ValueError("weights needs one number per rank (%d), got %d" % (self.world, len(weights)))
+            parts = [_nbx().partition_weighted(self.n, self.world, list(weights), r) for r in range(self.world)]  # host arithmetic of libnbx
+            if parts[0][0] < self.world:  # the same verdict on every rank, before any engine or collective exists
+                raise ValueError("n=%d bodies are %d tiles of 256 records: a world of %d ranks would leave rank(s) without bodies"
+                                 % (self.n, parts[0][0], self.world))
+            self.shares = [(p[1], p[2]) for p in parts]
+            self.i_begin, self.i_count = self.shares[self.rank]
+            self.n_alloc = parts[0][3]
+            self.block = max(c for _, c in self.shares)  # the largest share (reports); blocks differ in size
+        else:
+            check_world(self.n, self.world)  # collective decision: raises on all ranks or on none
+            self.block, self.i_begin, self.i_count, self.n_alloc = block_partition(self.n, self.world, self.rank)
         self.rec = 16 if precision == 32 else 32
         factory = engine_factory or NbxEngine
         self.engine = factory(self.n, precision, self.i_begin, self.i_count, self.n_alloc, **opts)
@@ -198,6 +214,20 @@ class ShardedSimulation:
     def _all_gather_in_place(self, full):
         """In-place all-gather: rank r contributes full[r*block : (r+1)*block] (in records)."""
         import torch
+        if self.shares is not None:
+            # unequal shares: every owner broadcasts its block in place (P small collectives instead of one all-gather)
+            staged = full.is_cuda and self.dist.get_backend() != "nccl"  # rehearsal only: several ranks sharing one GPU under gloo
+            for r, (b, c) in enumerate(self.shares):
+                blk = full[b * self.rec:(b + c) * self.rec]
+                if staged:
+                    host = blk.cpu()
+                    self.dist.broadcast(host, src=r)
+                    if r != self.rank:
+                        blk.copy_(host)
+                else:
+                    self.dist.broadcast(blk, src=r)
+            self.bytes_gathered += (self.n - self.i_count) * self.rec
+            return
         nb = self.block * self.rec
         own = full[self.rank * nb:(self.rank + 1) * nb]
         if full.is_cuda and self.dist.get_backend() != "nccl":

@@ -23,7 +23,9 @@ def main():
     else:
         dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    sim = sharded.ShardedSimulation(n, 32, dist=dist, force_collective=True, j_split=4, bodies_per_lane=2)
+    weights = [float(x) for x in os.environ["NBX_TEST_WEIGHTS"].split(",")] if os.environ.get("NBX_TEST_WEIGHTS") else None
+    shape = dict(summation_order=nbx.ORDER_REFERENCE) if weights else dict(j_split=4, bodies_per_lane=2)  # unequal shares: reference order is share-independent bit for bit
+    sim = sharded.ShardedSimulation(n, 32, dist=dist, force_collective=True, weights=weights, **shape)
     sim.upload(nbx.initial_conditions(n))
     ke = []
     for _ in range(steps):

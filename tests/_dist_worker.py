@@ -77,8 +77,9 @@ def main():
     n, steps, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    weights = [float(x) for x in os.environ["NBX_TEST_WEIGHTS"].split(",")] if os.environ.get("NBX_TEST_WEIGHTS") else None
     try:
-        sim = sharded.ShardedSimulation(n, 32, dist=dist, engine_factory=OracleEngine)
+        sim = sharded.ShardedSimulation(n, 32, dist=dist, engine_factory=OracleEngine, weights=weights)
     except ValueError as e:  # a world too large for n: every rank must get here (none may be left in a collective)
         with open("%s.%d" % (out, rank), "w") as f:
             json.dump({"rank": rank, "world": world, "refused": str(e)}, f)

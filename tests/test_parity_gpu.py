@@ -696,7 +696,7 @@ def test_fullsize_padding_bodies_are_inert(nbx):
 
 
 # ---- the product engine under torch.distributed (rehearsals possible on a 1-GPU box) ------------
-def _run_ranks(tmp_path, n, steps, world, backend):
+def _run_ranks(tmp_path, n, steps, world, backend, weights=None):
     import socket
     import subprocess
     import sys
@@ -706,6 +706,8 @@ def _run_ranks(tmp_path, n, steps, world, backend):
     s.close()
     out = str(tmp_path / "res")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    if weights:
+        env["NBX_TEST_WEIGHTS"] = weights
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", port,
            os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), str(n), str(steps), out, backend]
@@ -732,6 +734,21 @@ def test_product_engine_under_torch_distributed(nbx, tmp_path, world, backend):
         assert r["pos_x"] == px.tolist()[:64] + px.tolist()[-64:]
         assert rel_err(r["ke"], ke).max() < 1e-12
     assert sum(r["i_count"] for r in res) == n
+
+
+def test_product_engine_with_unequal_shares_under_torch_distributed(nbx, tmp_path):
+    """ShardedSimulation(weights=[1, 2, 1]) with the product engine: three ranks sharing cuda:0 over gloo, shares 768 / 1536 / 697 bodies,
+    one broadcast per owner and step -- bit-equal to one context in reference order."""
+    n, steps = 3001, 8
+    res = _run_ranks(tmp_path, n, steps, 3, "gloo", weights="1,2,1")
+    with nbx.Context(n, summation_order=nbx.ORDER_REFERENCE) as c:
+        c.upload(nbx.initial_conditions(n))
+        ke = c.step_trace(steps)
+        px = c.download()["pos_x"]
+    assert [r["i_count"] for r in res] == [768, 1536, 697] and all(r["n_alloc"] == 3072 for r in res)
+    for r in res:
+        assert r["pos_x"] == px.tolist()[:64] + px.tolist()[-64:]
+        assert rel_err(r["ke"], ke).max() < 1e-12
 
 
 # ---- T6: the drop-in executables -----------------------------------------------------------------

@@ -88,6 +88,30 @@ def test_gloo_ranks_reproduce_single_process_trace(oracle, tmp_path, n, world, s
         assert par["parity"] is None
 
 
+@pytest.mark.parametrize("n,world,weights,counts", [(1000, 2, "1,3", [256, 744]), (1500, 3, "2,1,1", [768, 512, 220])])
+def test_gloo_ranks_with_unequal_shares_reproduce_the_single_process_run(oracle, tmp_path, n, world, weights, counts):
+    """ShardedSimulation(weights=...): shares in whole 256-record tiles from libnbx's nbx_partition_weighted, the per-step exchange as one
+    in-place broadcast per owner -- every rank still ends every step with ALL positions, bit-identical to the single-process run."""
+    steps = 12
+    out = str(tmp_path / "res")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="2", NBX_TEST_WEIGHTS=weights)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
+           os.path.join(ROOT, "tests", "_dist_worker.py"), str(n), str(steps), out]
+    subprocess.run(cmd, env=env, check=True, timeout=300, capture_output=True)
+    res = [json.load(open("%s.%d" % (out, r))) for r in range(world)]
+    pos = [np.load("%s.%d.npy" % (out, r)) for r in range(world)]
+    s = oracle.init_state(n)
+    ke_ref = oracle.run(s, steps)
+    ref_pos = np.stack([s.pos_x, s.pos_y, s.pos_z], axis=1)
+    assert [x["i_count"] for x in res] == counts and [x["i_begin"] for x in res] == [sum(counts[:r]) for r in range(world)]
+    for r in range(world):
+        assert np.array_equal(pos[r], ref_pos), r
+        assert rel_err(res[r]["ke"], ke_ref).max() < 2e-6 and res[r]["ke"] == res[0]["ke"]
+        assert res[r]["bytes_gathered"] == steps * (n - counts[r]) * 16     # what the other owners broadcast
+        assert res[r]["n_alloc"] == -(-n // 256) * 256
+
+
 def test_rank_report_summary_arithmetic():
     """summarise_rank_reports is plain arithmetic: check it without any process group (and that a missing rank is an error)."""
     import sharded
