@@ -255,6 +255,28 @@ def test_kenergy_trace_fp32_small_and_ragged(nbx, name):
     assert np.allclose(fin["vel_z"][:k], g["final"]["vel_z"]["first"], rtol=1e-3, atol=1e-7)
 
 
+@pytest.mark.parametrize("name,steps,shape", [
+    ("ver7_f32_n65536_s20.json", 20, dict(bodies_per_lane=1, inner_loop=2)),   # two j records per packed operation, one workgroup per CU
+    ("ver7_f32_n65536_s20.json", 20, dict(bodies_per_lane=2, inner_loop=4)),   # two bodies per lane + L2 prefetch, 256-record trips
+    ("ver7_f32_n65536_s20.json", 20, dict(bodies_per_lane=4, inner_loop=4)),
+    ("ver7_f32_n4099_s40.json", 40, dict(bodies_per_lane=1, inner_loop=2)),    # ragged n: 17 workgroups, padding records in the last trip
+    ("ver7_f32_n1000_s100.json", 100, dict(bodies_per_lane=1, inner_loop=2)),
+    ("ver7_f32_n16384_s500.json", 200, dict(bodies_per_lane=1, inner_loop=2)),  # configs[1]'s size up to where it turns chaotic
+    ("ver7_f32_n262144_s7.json", 7, dict(bodies_per_lane=1, inner_loop=2)),     # four workgroups per CU: the loop off its home ground
+])
+def test_round4_loops_against_the_reference_binary_s_own_traces(nbx, name, steps, shape):
+    """The loops added in round 4 -- one body per lane with two j records per packed operation, and the L2-prefetch variant of the two- /
+    four-bodies-per-lane loop -- are bit-equal to the other reference-order shapes (tested elsewhere); here they face the REFERENCE:
+    per-step kenergy of its own binary (tests/golden/, oracle/gen_golden.py) within 1e-5 in reference summation order."""
+    g = load_golden(name)
+    ke, fin = _trace(nbx, g["n"], steps, summation_order=nbx.ORDER_REFERENCE, kernel_variant=nbx.KERNEL_SGPR, **shape)
+    err = rel_err(ke, g["kenergy"][:steps])
+    assert err.max() < 1e-5, (int(err.argmax()) + 1, err.max())
+    if steps == g["nsteps"]:
+        k = len(g["final"]["pos_x"]["first"])
+        assert np.allclose(fin["pos_x"][:k], g["final"]["pos_x"]["first"], rtol=1e-4, atol=1e-6)
+
+
 def test_kenergy_trace_config0_n2000_s500(nbx):
     """BASELINE.json configs[0]: kenergy at every step (not only the 10 printed ones) within 1e-4."""
     g = load_golden("ver7_f32_n2000_s500.json")
