@@ -1716,6 +1716,37 @@ def test_hand_scheduled_loop_bit_equal_over_random_sizes_slices_and_splits(nbx):
     assert checked >= 40, checked
 
 
+def test_two_records_per_operation_loop_bit_equal_over_random_sizes_slices_and_splits(nbx):
+    """The same for ONE body per lane (round 4): 50 seeded random combinations of ragged n, owned slice and j-split on the plain SGPR kernel
+    -- the loop that packs records j and j + 1 of the pair-interleaved copy into every packed instruction against the compiled loop of plain
+    instructions on the records themselves: accelerations and two steps, bit for bit (odd slice offsets, padding records, splits that begin
+    and end inside the array)."""
+    rng = np.random.default_rng(4242)
+    for _ in range(50):
+        n = int(rng.integers(300, 60000))
+        blk = -(-n // 256) * 256 + 256 * int(rng.integers(0, 3))
+        i_begin = int(rng.integers(0, max(1, n // 2)))
+        i_count = int(rng.integers(1, n - i_begin + 1))
+        S = int(rng.choice([1, 1, 2, 3, 5, 8]))
+        opts = dict(kernel_variant=nbx.KERNEL_SGPR, bodies_per_lane=1, j_split=S, i_begin=i_begin, i_count=i_count, n_alloc=blk, use_graph=int(rng.choice([1, 2])))
+        ic = nbx.initial_conditions(n)
+        with nbx.Context(n, 32, inner_loop=nbx.LOOP_ASM, **opts) as ca, nbx.Context(n, 32, inner_loop=nbx.LOOP_CXX, **opts) as cc:
+            out = []
+            for c in (ca, cc):
+                c.upload(ic)
+                acc = c.accel()
+                for _k in range(2):
+                    c.step_local()
+                    c.commit()
+                out.append((acc, c.download(), c.kenergy_partial()))
+            assert ca.stats()["inner_loop"] == nbx.LOOP_ASM and cc.stats()["inner_loop"] == nbx.LOOP_CXX and ca.stats()["bodies_per_lane"] == 1
+        for q in range(3):
+            assert np.array_equal(out[0][0][q], out[1][0][q]), (n, opts, q)
+        for f in out[0][1]:
+            assert np.array_equal(out[0][1][f], out[1][1][f]), (n, opts, f)
+        assert out[0][2] == out[1][2], (n, opts)
+
+
 @pytest.mark.parametrize("n,own,steps,B", [(262144, 262144, 2, 2), (262144, 262144, 1, 4), (131072, 131072, 3, 2), (16384, 16384, 12, 2),
                                             (4099, 4099, 25, 4), (524288, 65536, 1, 2)])
 def test_time_sliced_wave_priority_changes_no_bit(nbx, n, own, steps, B):
