@@ -1644,7 +1644,9 @@ def test_hand_scheduled_loop_in_the_wave_split_kernel_is_bit_equal_too(nbx, n, S
 
 def test_hand_scheduled_loop_bit_equal_on_adversarial_states(nbx):
     """Not only the seed-42 cloud: clustered bodies (many pairs at r^2 = softening), coincident bodies, masses spanning twelve
-    decades, zero masses, a far-away outlier -- whatever the operands, the two loops must produce the same bits."""
+    decades, zero masses, masses so small that G m / r^3 is a denormal number, a far-away outlier -- whatever the operands, the two
+    loops must produce the same bits.  One body per lane compares PACKED instructions (two j records per operation) with the compiled
+    loop's plain ones: the denormal terms are where the two instruction families could have differed."""
     rng = np.random.default_rng(7)
     n = 8192
     st8 = {f: np.zeros(n, dtype=np.float32) for f in nbx.FIELDS}
@@ -1659,8 +1661,10 @@ def test_hand_scheduled_loop_bit_equal_on_adversarial_states(nbx):
         st8[f] = (1e-3 * rng.standard_normal(n)).astype(np.float32)
     st8["mass"] = (np.float32(10.0) ** rng.uniform(-6, 6, n).astype(np.float32)).astype(np.float32)
     st8["mass"][::13] = 0.0
+    st8["mass"][3::29] = np.float32(1e-22)   # G m = 6.7e-33: times 1 / r^3 of the outlier (3.7e-11) far below the smallest normal float
+    st8["mass"][4::31] = np.float32(3e-26)
     for variant, shapes in ((nbx.KERNEL_SGPR, (dict(j_split=1), dict(j_split=4))), (nbx.KERNEL_SGPRW, (dict(j_split=8),))):
-        for B in (2, 4):
+        for B in ((1, 2, 4) if variant == nbx.KERNEL_SGPR else (2, 4)):
             for shape in shapes:
                 res = []
                 for loop in (nbx.LOOP_ASM, nbx.LOOP_CXX):
