@@ -210,12 +210,14 @@ def parity_probe_sharded(sim, ic, n, precision, rank):
             "gate": 1e-4, "pass": max(err) < 1e-4, "ranks": sim.world}, ke
 
 
-def _free_port():
+def _reserve_port():
+    """A free TCP port and the socket that holds it: bound with SO_REUSEADDR and never listening, so that nbody.x's rendezvous (which
+    sets SO_REUSEADDR too) can bind and listen on the same port while nobody else can take it in between (bind-then-close
+    was a time-of-check / time-of-use race).  Keep the socket until the children are done."""
     s = socket.socket()
+    s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
     s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    return s, s.getsockname()[1]
 
 
 def native_rank_group_check(dist, rank, world, device, n, precision, ke_torch_path, window=10):
@@ -233,7 +235,8 @@ def native_rank_group_check(dist, rank, world, device, n, precision, ke_torch_pa
     if len(set(hosts)) > 1:
         # the children rendezvous on 127.0.0.1: ranks on other nodes would wait out NBODY_RENDEZVOUS_TIMEOUT for nothing
         return {"skipped": "ranks on %d hosts: this leg starts its children on one node only" % len(set(hosts))} if rank == 0 else None
-    port = [_free_port() if rank == 0 else None]
+    hold, p0 = _reserve_port() if rank == 0 else (None, None)
+    port = [p0]
     dist.broadcast_object_list(port, src=0)
     exe = os.path.join(PKG, "host", "nbody.x" if precision == 32 else "nbody_fp64.x")
     res = {"rank": rank, "returncode": None}
@@ -258,6 +261,8 @@ def native_rank_group_check(dist, rank, world, device, n, precision, ke_torch_pa
         res["wall_s"] = time.perf_counter() - t0
     allres = [None] * world
     dist.all_gather_object(allres, res)
+    if hold is not None:
+        hold.close()
     if rank != 0:
         return None
     out = {"binary": os.path.relpath(exe, ROOT), "ranks": world, "steps": 2 * window, "returncodes": [r["returncode"] for r in allres],
